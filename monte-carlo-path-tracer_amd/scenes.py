@@ -1,0 +1,351 @@
+"""Synthetic stand-ins for the cg24 scenes the reference renders (cornell-box, veach-mis, bathroom2).
+
+The real scene folders are git-ignored in the reference (``.gitignore:3``, ``src/main.cpp:7-12``) and are
+not available offline, so every test / bench / golden vector uses the generators below.
+A scene is produced in the reference's own ``Model`` layout (``src/model.h:51-60``): indexed ``vertex`` /
+``normal`` / ``texture`` arrays in fp64, ``face`` = imat3x4 rows ``[v, vn, vt, material]`` per corner,
+``materials`` and ``camerainfo`` -- and can be written as the OBJ + MTL + XML triple the reference's
+``Model(filename)`` parses (``src/model.cpp:44-281``).
+
+All numbers are first formatted as text and then parsed back, so the arrays handed to the HIP library are
+bit-identical to what the reference's ``stringstream >> double`` / ``stod`` produce from the files.
+Every face corner uses equal v/vt/vn indices (the reference swaps vt and vn).
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+
+def _q(x: float) -> float:
+    """Round-trip through the text form used in the files (9 significant digits)."""
+    return float("%.9g" % x)
+
+
+@dataclass
+class Material:
+    name: str
+    kd: tuple = (0.0, 0.0, 0.0)
+    ks: tuple = (0.0, 0.0, 0.0)
+    ns: float = 1.0
+    radiance: tuple = (0.0, 0.0, 0.0)     # from the XML <light mtlname radiance> (model.cpp:264-279)
+    map_kd: Optional[str] = None          # texture file name (relative to the mtl), if any
+    texture: Optional[np.ndarray] = None  # HxWx3 uint8 image behind map_kd
+
+
+@dataclass
+class Camera:
+    eye: tuple
+    lookat: tuple
+    up: tuple
+    fovy: float
+    width: int
+    height: int
+
+
+@dataclass
+class SceneData:
+    name: str
+    vertex: np.ndarray      # (nv,3) f64
+    normal: np.ndarray      # (nn,3) f64
+    texcoord: np.ndarray    # (nt,2) f64
+    face: np.ndarray        # (nf,3,4) int32: per corner [v, vn, vt, material]  (glm::imat3x4, model.h:57)
+    materials: List[Material]
+    camera: Camera
+    meta: Dict = field(default_factory=dict)
+
+    @property
+    def n_faces(self) -> int:
+        return int(self.face.shape[0])
+
+    def with_resolution(self, w: int, h: int) -> "SceneData":
+        cam = Camera(self.camera.eye, self.camera.lookat, self.camera.up, self.camera.fovy, int(w), int(h))
+        return SceneData(self.name, self.vertex, self.normal, self.texcoord, self.face, self.materials, cam, dict(self.meta))
+
+    # ------------------------------------------------------------------ file output
+    def write(self, directory: str) -> str:
+        """Write <name>.obj / .mtl / .xml (+ textures as binary PPM) and return the .obj path."""
+        os.makedirs(directory, exist_ok=True)
+        obj = os.path.join(directory, self.name + ".obj")
+        with open(obj, "w") as f:
+            f.write("mtllib %s.mtl\n" % self.name)
+            for v in self.vertex:
+                f.write("v %.9g %.9g %.9g\n" % tuple(v))
+            for n in self.normal:
+                f.write("vn %.9g %.9g %.9g\n" % tuple(n))
+            for t in self.texcoord:
+                f.write("vt %.9g %.9g\n" % tuple(t))
+            cur = -1
+            for fc in self.face:
+                m = int(fc[0, 3])
+                if m != cur:
+                    f.write("usemtl %s\n" % self.materials[m].name)
+                    cur = m
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (
+                    fc[0, 0] + 1, fc[0, 1] + 1, fc[0, 2] + 1,
+                    fc[1, 0] + 1, fc[1, 1] + 1, fc[1, 2] + 1,
+                    fc[2, 0] + 1, fc[2, 1] + 1, fc[2, 2] + 1))
+        with open(os.path.join(directory, self.name + ".mtl"), "w") as f:
+            for m in self.materials:
+                f.write("newmtl %s\n" % m.name)
+                f.write("Kd %.9g %.9g %.9g\n" % tuple(m.kd))
+                f.write("Ks %.9g %.9g %.9g\n" % tuple(m.ks))
+                f.write("Ns %.9g\n" % m.ns)
+                if m.map_kd is not None:
+                    f.write("map_Kd %s\n" % m.map_kd)
+                    write_ppm(os.path.join(directory, m.map_kd), m.texture)
+                f.write("\n")
+        c = self.camera
+        with open(os.path.join(directory, self.name + ".xml"), "w") as f:
+            f.write('<?xml version="1.0" encoding="utf-8"?>\n')
+            f.write('<camera type="perspective" width="%d" height="%d" fovy="%.9g">\n' % (c.width, c.height, c.fovy))
+            f.write('  <eye x="%.9g" y="%.9g" z="%.9g"/>\n' % tuple(c.eye))
+            f.write('  <lookat x="%.9g" y="%.9g" z="%.9g"/>\n' % tuple(c.lookat))
+            f.write('  <up x="%.9g" y="%.9g" z="%.9g"/>\n' % tuple(c.up))
+            f.write('</camera>\n')
+            for m in self.materials:
+                if any(r != 0 for r in m.radiance):
+                    f.write('<light mtlname="%s" radiance="%.9g,%.9g,%.9g"/>\n' % ((m.name,) + tuple(m.radiance)))
+        return obj
+
+
+def write_ppm(path: str, img: np.ndarray) -> None:
+    """Binary P6 -- a format stb_image (the reference's texture loader, model.cpp:8-23) reads."""
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(img.tobytes())
+
+
+class _Mesh:
+    """Accumulates unified-index geometry (one v / vn / vt triple per corner index)."""
+
+    def __init__(self):
+        self.v: List[tuple] = []
+        self.n: List[tuple] = []
+        self.t: List[tuple] = []
+        self.f: List[tuple] = []   # (i0, i1, i2, material)
+
+    def add_vertex(self, p, n, uv) -> int:
+        self.v.append(tuple(_q(float(x)) for x in p))
+        self.n.append(tuple(_q(float(x)) for x in n))
+        self.t.append(tuple(_q(float(x)) for x in uv))
+        return len(self.v) - 1
+
+    def add_tri(self, a, b, c, mat):
+        self.f.append((a, b, c, mat))
+
+    def add_quad(self, p0, p1, p2, p3, n, mat, uv=((0, 0), (1, 0), (1, 1), (0, 1))):
+        i = [self.add_vertex(p, n, t) for p, t in zip((p0, p1, p2, p3), uv)]
+        self.add_tri(i[0], i[1], i[2], mat)
+        self.add_tri(i[0], i[2], i[3], mat)
+
+    def add_grid(self, origin, du, dv, nu, nv, n, mat, uv_scale=1.0):
+        """A planar rectangle origin + s*du + t*dv tessellated into nu x nv cells."""
+        o = np.asarray(origin, float); du = np.asarray(du, float); dv = np.asarray(dv, float)
+        idx = [[self.add_vertex(o + du * (i / nu) + dv * (j / nv), n, (uv_scale * i / nu, uv_scale * j / nv))
+                for i in range(nu + 1)] for j in range(nv + 1)]
+        for j in range(nv):
+            for i in range(nu):
+                a, b, c, d = idx[j][i], idx[j][i + 1], idx[j + 1][i + 1], idx[j + 1][i]
+                self.add_tri(a, b, c, mat)
+                self.add_tri(a, c, d, mat)
+
+    def add_uv_sphere(self, center, radius, n_lon, n_lat, mat, flip=False):
+        """UV sphere, smooth normals; n_lon*(n_lat-1)*2 triangles."""
+        cx, cy, cz = center
+        rows = []
+        for j in range(n_lat + 1):
+            th = math.pi * j / n_lat
+            row = []
+            for i in range(n_lon + 1):
+                ph = 2.0 * math.pi * i / n_lon
+                d = (math.sin(th) * math.cos(ph), math.cos(th), math.sin(th) * math.sin(ph))
+                nn = tuple(-x for x in d) if flip else d
+                row.append(self.add_vertex((cx + radius * d[0], cy + radius * d[1], cz + radius * d[2]), nn,
+                                           (i / n_lon, j / n_lat)))
+            rows.append(row)
+        for j in range(n_lat):
+            for i in range(n_lon):
+                a, b, c, d = rows[j][i], rows[j][i + 1], rows[j + 1][i + 1], rows[j + 1][i]
+                if j != 0:
+                    self.add_tri(a, b, c, mat)
+                if j != n_lat - 1:
+                    self.add_tri(a, c, d, mat)
+
+    def finish(self, name, materials, camera, meta=None) -> SceneData:
+        v = np.asarray(self.v, np.float64).reshape(-1, 3)
+        n = np.asarray(self.n, np.float64).reshape(-1, 3)
+        t = np.asarray(self.t, np.float64).reshape(-1, 2)
+        # the reference keeps the file's face order but needs `usemtl` runs; keep insertion order
+        face = np.zeros((len(self.f), 3, 4), np.int32)
+        for k, (a, b, c, m) in enumerate(self.f):
+            for j, idx in enumerate((a, b, c)):
+                face[k, j, 0] = idx; face[k, j, 1] = idx; face[k, j, 2] = idx; face[k, j, 3] = m
+        return SceneData(name, v, n, t, face, materials, camera, meta or {})
+
+
+def _qcam(eye, lookat, up, fovy, w, h) -> Camera:
+    return Camera(tuple(_q(x) for x in eye), tuple(_q(x) for x in lookat), tuple(_q(x) for x in up), _q(fovy), int(w), int(h))
+
+
+# ---------------------------------------------------------------------------------------------- S-cornell
+def cornell_box(width=800, height=800, sphere_lon=200, sphere_lat=100, wall_cells=1) -> SceneData:
+    """S-cornell: unit box, five diffuse walls, ceiling quad light (17,12,4), glossy UV sphere.
+
+    Default tessellation gives 200*(100-1)*2 = 39 600 sphere triangles + 10 wall + 2 light triangles.
+    """
+    mats = [
+        Material("white", kd=(0.725, 0.71, 0.68)),
+        Material("red", kd=(0.63, 0.065, 0.05)),
+        Material("green", kd=(0.14, 0.45, 0.091)),
+        Material("light", kd=(0.65, 0.65, 0.65), radiance=(17.0, 12.0, 4.0)),
+        Material("glossy", kd=(0.3, 0.3, 0.3), ks=(0.5, 0.5, 0.5), ns=50.0),
+    ]
+    WHITE, RED, GREEN, LIGHT, GLOSSY = range(5)
+    m = _Mesh()
+    c = wall_cells
+    m.add_grid((0, 0, 0), (1, 0, 0), (0, 0, 1), c, c, (0, 1, 0), WHITE)      # floor
+    m.add_grid((0, 1, 0), (1, 0, 0), (0, 0, 1), c, c, (0, -1, 0), WHITE)     # ceiling
+    m.add_grid((0, 0, 0), (1, 0, 0), (0, 1, 0), c, c, (0, 0, 1), WHITE)      # back wall
+    m.add_grid((0, 0, 0), (0, 0, 1), (0, 1, 0), c, c, (1, 0, 0), RED)        # left
+    m.add_grid((1, 0, 0), (0, 0, 1), (0, 1, 0), c, c, (-1, 0, 0), GREEN)     # right
+    m.add_quad((0.35, 0.999, 0.35), (0.65, 0.999, 0.35), (0.65, 0.999, 0.65), (0.35, 0.999, 0.65), (0, -1, 0), LIGHT)
+    m.add_uv_sphere((0.5, 0.3, 0.5), 0.3, sphere_lon, sphere_lat, GLOSSY)
+    cam = _qcam((0.5, 0.5, 2.3), (0.5, 0.5, 0.0), (0, 1, 0), 40.0, width, height)
+    return m.finish("cornell-box", mats, cam, {"kind": "S-cornell"})
+
+
+def cornell_box_small(width=64, height=64) -> SceneData:
+    """Cheap variant for CPU tests: same box, 24x12 sphere (528 triangles)."""
+    return cornell_box(width, height, sphere_lon=24, sphere_lat=12)
+
+
+# ---------------------------------------------------------------------------------------------- S-veach
+def veach_mis(width=1280, height=720, light_lon=32, light_lat=16, plate_cells=8) -> SceneData:
+    """S-veach: four Blinn-Phong plates Ns in {10,100,1000,5000}, four sphere lights of radii
+    {.03,.1,.3,.9} with equal power, a diffuse floor and back wall."""
+    radii = (0.03, 0.1, 0.3, 0.9)
+    base = 800.0 * radii[0] ** 2       # radiance * r^2 constant -> equal power
+    mats = [Material("backdrop", kd=(0.4, 0.4, 0.4))]
+    for ns in (10.0, 100.0, 1000.0, 5000.0):
+        mats.append(Material("plate%d" % int(ns), kd=(0.07, 0.09, 0.13), ks=(0.5, 0.5, 0.5), ns=ns))
+    cols = ((1.0, 0.9, 0.8), (0.9, 1.0, 0.85), (0.8, 0.9, 1.0), (1.0, 0.85, 0.95))
+    for r, col in zip(radii, cols):
+        e = base / (r * r)
+        mats.append(Material("light%d" % int(r * 100), kd=(0.0, 0.0, 0.0), radiance=tuple(_q(e * c) for c in col)))
+    m = _Mesh()
+    m.add_grid((-8, -0.2, -6), (16, 0, 0), (0, 0, 14), 4, 4, (0, 1, 0), 0)          # floor
+    m.add_grid((-8, -0.2, -6), (16, 0, 0), (0, 10, 0), 4, 4, (0, 0, 1), 0)          # back wall
+    # plates: tilted towards the camera so each reflects the row of lights
+    for k, tilt in enumerate((28.0, 22.0, 16.0, 10.0)):
+        z0 = 1.8 - 1.25 * k
+        y0 = 0.0 + 0.28 * k
+        a = math.radians(tilt)
+        dv = (0.0, math.sin(a) * 1.0, -math.cos(a) * 1.0)
+        nrm = (0.0, math.cos(a), math.sin(a))
+        m.add_grid((-3.2, y0, z0), (6.4, 0, 0), dv, plate_cells, max(1, plate_cells // 4), nrm, 1 + k)
+    for k, r in enumerate(radii):
+        m.add_uv_sphere((-2.7 + 1.8 * k, 2.6, -1.9), r, light_lon, light_lat, 5 + k)
+    cam = _qcam((0.0, 2.2, 9.5), (0.0, 0.9, 0.0), (0, 1, 0), 30.0, width, height)
+    return m.finish("veach-mis", mats, cam, {"kind": "S-veach"})
+
+
+# ---------------------------------------------------------------------------------------------- S-bath
+def value_noise_texture(size: int, seed: int, base=(0.6, 0.6, 0.6), amp=0.35) -> np.ndarray:
+    """Seeded multi-octave value noise, 3 channels, uint8 (stand-in for the bathroom's tile/wood images)."""
+    rng = np.random.RandomState(seed)
+    img = np.zeros((size, size, 3), np.float64)
+    for octave in range(5):
+        cells = 4 << octave
+        g = rng.rand(cells + 1, cells + 1, 3)
+        xs = np.linspace(0, cells, size, endpoint=False)
+        i = xs.astype(int); f = xs - i
+        f = f * f * (3 - 2 * f)
+        a = g[i][:, i]; b = g[i][:, i + 1]; c = g[i + 1][:, i]; d = g[i + 1][:, i + 1]
+        fx = f[None, :, None]; fy = f[:, None, None]
+        img += ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy) / (2 ** octave)
+    img = img / img.max()
+    out = np.clip(np.asarray(base)[None, None, :] + amp * (img - 0.5) * 2.0, 0.0, 1.0)
+    return (out * 255.0 + 0.5).astype(np.uint8)
+
+
+def bathroom_stress(width=1920, height=1080, detail=64, tex_size=256) -> SceneData:
+    """S-bath: a procedural room -- textured floor / walls, a mirror (Ns=10000), glossy
+    fixtures built from tessellated spheres and a bumpy displaced "towel" grid, lit by a window quad.
+    Triangle count grows ~ detail^2: detail=64 -> ~0.12 M, detail=160 -> ~0.6 M, detail=420 -> ~4.1 M."""
+    mats = [
+        Material("floor", kd=(0.6, 0.6, 0.6), map_kd="floor.ppm", texture=value_noise_texture(tex_size, 1, (0.55, 0.5, 0.45))),
+        Material("wall", kd=(0.7, 0.7, 0.7), map_kd="wall.ppm", texture=value_noise_texture(tex_size, 2, (0.7, 0.72, 0.75), 0.2)),
+        Material("wood", kd=(0.4, 0.3, 0.2), ks=(0.1, 0.1, 0.1), ns=30.0, map_kd="wood.ppm",
+                 texture=value_noise_texture(tex_size, 3, (0.45, 0.3, 0.18), 0.3)),
+        Material("towel", kd=(0.7, 0.2, 0.2), map_kd="towel.ppm", texture=value_noise_texture(tex_size, 4, (0.7, 0.25, 0.25), 0.25)),
+        Material("mirror", kd=(0.0, 0.0, 0.0), ks=(1.0, 1.0, 1.0), ns=10000.0),
+        Material("ceramic", kd=(0.8, 0.8, 0.8), ks=(0.4, 0.4, 0.4), ns=400.0),
+        Material("chrome", kd=(0.05, 0.05, 0.05), ks=(0.8, 0.8, 0.8), ns=2000.0),
+        Material("window", kd=(0.0, 0.0, 0.0), radiance=(25.0, 23.0, 20.0)),
+    ]
+    FLOOR, WALL, WOOD, TOWEL, MIRROR, CERAMIC, CHROME, WINDOW = range(8)
+    m = _Mesh()
+    W, H, D = 4.0, 2.6, 5.0
+    g = max(2, detail // 4)
+    m.add_grid((0, 0, 0), (W, 0, 0), (0, 0, D), g, g, (0, 1, 0), FLOOR, uv_scale=4.0)
+    m.add_grid((0, H, 0), (W, 0, 0), (0, 0, D), g, g, (0, -1, 0), WALL, uv_scale=2.0)
+    m.add_grid((0, 0, 0), (W, 0, 0), (0, H, 0), g, g, (0, 0, 1), WALL, uv_scale=3.0)
+    m.add_grid((0, 0, 0), (0, 0, D), (0, H, 0), g, g, (1, 0, 0), WALL, uv_scale=3.0)
+    m.add_grid((W, 0, 0), (0, 0, D), (0, H, 0), g, g, (-1, 0, 0), WALL, uv_scale=3.0)
+    m.add_grid((0, 0, D), (W, 0, 0), (0, H, 0), g, g, (0, 0, -1), WALL, uv_scale=3.0)
+    m.add_quad((0.8, 1.0, 0.01), (2.6, 1.0, 0.01), (2.6, 2.2, 0.01), (0.8, 2.2, 0.01), (0, 0, 1), MIRROR)
+    m.add_quad((W - 0.01, 1.2, 1.5), (W - 0.01, 1.2, 3.2), (W - 0.01, 2.3, 3.2), (W - 0.01, 2.3, 1.5), (-1, 0, 0), WINDOW)
+    # vanity: a box of wood grids
+    m.add_grid((0.6, 0.85, 0.05), (2.2, 0, 0), (0, 0, 0.7), g, g, (0, 1, 0), WOOD, uv_scale=2.0)
+    m.add_grid((0.6, 0.0, 0.75), (2.2, 0, 0), (0, 0.85, 0), g, g, (0, 0, 1), WOOD, uv_scale=2.0)
+    # fixtures: spheres with ~detail^2 triangles each
+    lon, lat = 2 * detail, detail
+    m.add_uv_sphere((1.7, 0.95, 0.4), 0.22, lon, lat, CERAMIC)          # basin
+    m.add_uv_sphere((1.7, 1.25, 0.12), 0.05, lon // 2, lat // 2, CHROME)   # tap
+    m.add_uv_sphere((3.2, 0.45, 4.0), 0.45, lon, lat, CERAMIC)          # tub end
+    m.add_uv_sphere((0.6, 0.35, 3.6), 0.35, lon, lat, CERAMIC)          # stool
+    m.add_uv_sphere((2.2, 0.2, 2.4), 0.2, lon // 2, lat // 2, CHROME)
+    # towel: displaced grid hanging on the left wall (bumpy -> deep, irregular BVH)
+    nu = nv = 2 * detail
+    o = np.array((0.05, 0.9, 2.0)); du = np.array((0.0, 0.0, 1.2)); dv = np.array((0.0, 1.0, 0.0))
+    rows = []
+    for j in range(nv + 1):
+        row = []
+        for i in range(nu + 1):
+            s, t = i / nu, j / nv
+            bump = 0.03 * math.sin(40 * s) * math.cos(34 * t) + 0.02 * math.sin(91 * s + 57 * t)
+            p = o + du * s + dv * t + np.array((0.06 + bump, 0, 0))
+            nx = np.array((1.0, -0.03 * 34 * -math.sin(40 * s) * math.sin(34 * t), -0.03 * 40 * math.cos(40 * s) * math.cos(34 * t)))
+            nx /= np.linalg.norm(nx)
+            row.append(m.add_vertex(p, nx, (s * 2, t * 2)))
+        rows.append(row)
+    for j in range(nv):
+        for i in range(nu):
+            a, b, c, d = rows[j][i], rows[j][i + 1], rows[j + 1][i + 1], rows[j + 1][i]
+            m.add_tri(a, b, c, TOWEL); m.add_tri(a, c, d, TOWEL)
+    cam = _qcam((2.0, 1.5, 4.7), (1.8, 1.1, 0.0), (0, 1, 0), 55.0, width, height)
+    return m.finish("bathroom2", mats, cam, {"kind": "S-bath", "detail": detail})
+
+
+# tiny scenes for KATs ------------------------------------------------------------------------------
+def open_box(width=32, height=32) -> SceneData:
+    """14-triangle Cornell box without the sphere (the survey's smallest probe scene)."""
+    s = cornell_box(width, height, sphere_lon=3, sphere_lat=2)
+    keep = [k for k in range(s.n_faces) if s.face[k, 0, 3] != 4]
+    s2 = SceneData("open-box", s.vertex, s.normal, s.texcoord, s.face[keep].copy(), s.materials, s.camera, {"kind": "open-box"})
+    return s2
+
+
+SCENES = {
+    "cornell-box": cornell_box,
+    "cornell-box-small": cornell_box_small,
+    "veach-mis": veach_mis,
+    "bathroom2": bathroom_stress,
+    "open-box": open_box,
+}
