@@ -1,0 +1,184 @@
+/* mcpt.h -- C ABI of the MI355X-native path-tracing hot path (libmcpt_hip.so).
+ *
+ * Drop-in boundary for laizesheng1/Monte-Carlo-Path-Tracer's `Render` class: everything a caller hands
+ * over is the reference's own `Model` data (src/model.h:51-60) as plain pointers + counts, and what it
+ * gets back is the reference's film accumulator `Pixels{vec3 color; float spp}` (src/Scene.h:7-12).
+ * The reference has no FFI layer (it is one C++ executable); the entry points below are what a binding
+ * for its Render::Render / Render::render pair would call -- see INTEGRATION.md for the ~40-line
+ * `Render` replacement a maintainer would add.
+ *
+ * Plain C, no HIP / torch / STL types.  Every function returns an mcpt_status; nothing throws.
+ * There is NO CPU fallback: without a usable HIP device mcpt_create fails with MCPT_ERR_NO_DEVICE.
+ */
+#ifndef MCPT_H
+#define MCPT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCPT_ABI_VERSION 1
+
+typedef enum mcpt_status {
+    MCPT_OK = 0,
+    MCPT_ERR_INVALID_ARG = 1,   /* null pointer, out-of-range index in `face`, zero-sized image ... */
+    MCPT_ERR_NO_DEVICE = 2,     /* no HIP device / device ordinal out of range */
+    MCPT_ERR_HIP = 3,           /* a HIP runtime call failed; see mcpt_last_error() */
+    MCPT_ERR_NO_LIGHTS = 4,     /* scene has no emissive triangle (reference: UB, Render.cpp:204-206) */
+    MCPT_ERR_BVH_DEPTH = 5,     /* BVH deeper than the traversal stack the kernels were built for */
+    MCPT_ERR_UNSUPPORTED = 6
+} mcpt_status;
+
+/* Texture (src/model.h:21-30): `image_color` as w*h RGB fp32 texels, row 0 first as stb_image returns
+ * them (src/model.cpp:8-23).  A 1x1 texture is the constant Kd colour (model.cpp:25-28,32-35). */
+typedef struct mcpt_texture {
+    int32_t width, height;
+    const float* rgb;
+} mcpt_texture;
+
+/* Material (src/model.h:32-40).  Tr and Ni are parsed by the reference but never read (SURVEY A-21). */
+typedef struct mcpt_material {
+    double ks[3];
+    double ns;
+    double radiance[3];   /* from the XML <light mtlname radiance> (model.cpp:181-182) */
+    int32_t map_kd;       /* index into textures[] (Map_Kd) */
+    int32_t reserved;
+} mcpt_material;
+
+/* CameraInfo (src/model.h:42-49) */
+typedef struct mcpt_camera {
+    double eye[3], lookat[3], up[3];
+    double fovy;          /* vertical field of view in degrees (Render.cpp:73) */
+    int32_t width, height;
+} mcpt_camera;
+
+/* Model (src/model.h:51-60) */
+typedef struct mcpt_scene_desc {
+    const double* vertex;   uint32_t n_vertex;    /* xyz per vertex   (Model::vertex)  */
+    const double* normal;   uint32_t n_normal;    /* xyz per normal   (Model::normal)  */
+    const double* texcoord; uint32_t n_texcoord;  /* uv per entry     (Model::texture) */
+    const int32_t* face;    uint32_t n_face;      /* 12 ints per face = glm::imat3x4 (Model::face): for each of the
+                                                     3 corners {vertex idx, normal idx, texcoord idx, material idx},
+                                                     0-based; the material of a face is corner 0's (Render.cpp:33) */
+    const mcpt_material* materials; uint32_t n_materials;
+    const mcpt_texture* textures;   uint32_t n_textures;
+    mcpt_camera camera;
+} mcpt_scene_desc;
+
+/* integrators */
+#define MCPT_INTEGRATOR_MIS            0u  /* Render::ray_tracing(Ray&)      Render.cpp:111-175 -- the one that ships */
+#define MCPT_INTEGRATOR_RECURSIVE_NEE  1u  /* Render::ray_tracing(Ray&,int)  Render.cpp:83-109 + sample_light :177-200 */
+
+/* flags */
+#define MCPT_FLAG_CORRECT_SHADOW_T2   0x1u  /* do NOT reproduce the reference's light self-occlusion (SURVEY A-9):
+                                               the sampled light triangle is ignored by its own shadow ray */
+#define MCPT_FLAG_DETERMINISTIC       0x2u  /* one thread owns a pixel for the whole call: no float atomics,
+                                               bit-reproducible accumulator, worse tail balance */
+#define MCPT_FLAG_COUNT_TRAVERSAL     0x4u  /* also count box tests / triangle tests / shaded hits (roofline input) */
+
+typedef struct mcpt_opts {
+    uint32_t struct_size;       /* = sizeof(mcpt_opts) */
+    int32_t  device;            /* HIP device ordinal */
+    uint32_t max_depth;         /* 0 = unbounded like the reference; N = stop before shading vertex N
+                                   (`for (bounces = 0; bounces < N; ...)`, Render.cpp:116) */
+    uint32_t integrator;        /* MCPT_INTEGRATOR_* */
+    uint32_t flags;             /* MCPT_FLAG_* */
+    uint32_t samples_per_item;  /* samples of one pixel traced back-to-back by one lane; 0 = auto */
+    uint32_t reserved[4];
+} mcpt_opts;
+
+typedef struct mcpt_counters {
+    uint64_t paths;             /* pixel-samples finished */
+    uint64_t rays_primary;      /* camera rays traced (Render.cpp:64) */
+    uint64_t rays_continuation; /* BSDF-sampled rays traced (Render.cpp:144); the reference's duplicate re-trace
+                                   at Render.cpp:118 is never performed and never counted */
+    uint64_t rays_shadow;       /* shadow rays traced, i.e. light samples with pdf != 0 (Render.cpp:125) */
+    uint64_t box_tests;         /* AABB slab tests        (only with MCPT_FLAG_COUNT_TRAVERSAL) */
+    uint64_t tri_tests;         /* triangle tests         (only with MCPT_FLAG_COUNT_TRAVERSAL) */
+    uint64_t shaded_hits;       /* hits whose shading record was fetched (only with COUNT_TRAVERSAL) */
+    uint64_t texel_fetches;     /* image-texture lookups  (only with COUNT_TRAVERSAL) */
+    uint64_t self_shadow_tests; /* light samples that reached the fp64 self-hit predicate (A-9) */
+    uint64_t self_shadow_hits;  /* ... and were rejected by it */
+    double   kernel_ms;         /* HIP-event time of the render kernels of the LAST mcpt_render call */
+    uint64_t launches;          /* render kernel launches so far */
+} mcpt_counters;
+
+typedef struct mcpt_scene_info {
+    uint32_t n_tris, n_lights, n_nodes, bvh_depth, max_leaf;
+    uint32_t width, height;
+    uint64_t device_bytes;      /* HBM held by the scene (nodes + triangle streams + textures + accumulator) */
+    double   bvh_build_ms, upload_ms;
+} mcpt_scene_info;
+
+typedef struct mcpt_ctx mcpt_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------------------- */
+/* Replaces Render::Render(Model&) (Render.cpp:5-10): copies what it needs from `scene` (the caller may free it
+ * afterwards, like the reference's by-value `model` member, Render.h:57), flattens faces into triangles and
+ * collects emissive ones as lights (tranform_triangle, Render.cpp:12-44), builds the BVH (BVH.cpp:6-54) and
+ * uploads everything to HBM.  Allocates a zeroed width*height accumulator. */
+mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcpt_ctx** out_ctx);
+mcpt_status mcpt_destroy(mcpt_ctx* ctx);
+mcpt_status mcpt_get_scene_info(const mcpt_ctx* ctx, mcpt_scene_info* out);
+const char* mcpt_last_error(void);   /* thread-local, valid until the next failing call on this thread */
+uint32_t    mcpt_abi_version(void);
+
+/* ---- the hot path ----------------------------------------------------------------------------------- */
+/* Replaces `spp` consecutive calls of Render::render(Scene&) (Render.cpp:56-69): adds `spp` samples to EVERY
+ * pixel of the device accumulator (sum rgb + sample count, NaN components zeroed first like Scene::set_Pixel,
+ * Scene.cpp:12-21).  Samples are numbered first_sample .. first_sample+spp-1; a sample's random numbers depend
+ * only on (seed, pixel, sample index), so any split of a sample range over calls, GPUs or ranks yields the
+ * same image up to fp32 summation order.  Asynchronous on the context's stream. */
+mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t first_sample);
+mcpt_status mcpt_sync(mcpt_ctx* ctx);
+
+/* Film = Scene::m_Pixels (Scene.h:7-12,25): width*height records {r_sum, g_sum, b_sum, spp}, index y*width+x,
+ * y = 0 at the image bottom (Render.cpp:63, Scene.cpp:14). */
+mcpt_status mcpt_read_accum(mcpt_ctx* ctx, float* rgba_host);     /* synchronises, then D2H */
+mcpt_status mcpt_write_accum(mcpt_ctx* ctx, const float* rgba_host);   /* resume / merge */
+mcpt_status mcpt_clear_accum(mcpt_ctx* ctx);
+/* Scene::getPixelsColor (Scene.cpp:23-33) on the device: mean -> clamp[0,1] -> pow(.,0.5) -> *255.99 -> u8.
+ * flip_y != 0 additionally applies Scene::save_image's vertical flip (Scene.cpp:40-46). */
+mcpt_status mcpt_tonemap(mcpt_ctx* ctx, uint8_t* rgb_host, int flip_y);
+
+mcpt_status mcpt_get_counters(mcpt_ctx* ctx, mcpt_counters* out);  /* synchronises */
+mcpt_status mcpt_reset_counters(mcpt_ctx* ctx);
+
+/* ---- plumbing for multi-GPU hosts (one context per GPU / rank) ---------------------------------------- */
+/* Use a caller-owned device buffer of width*height*4 floats as the accumulator (e.g. a torch tensor that
+ * torch.distributed / RCCL all-reduces in place).  NULL re-binds the internal buffer. */
+mcpt_status mcpt_bind_accum(mcpt_ctx* ctx, void* device_rgba);
+mcpt_status mcpt_accum_device_ptr(mcpt_ctx* ctx, void** out_device_rgba);
+/* Launch on a caller-owned hipStream_t (NULL = the context's own stream). */
+mcpt_status mcpt_set_stream(mcpt_ctx* ctx, void* hip_stream);
+
+/* ---- function-level probes (what the parity tests call; each maps to one reference function) ---------- */
+/* BVH::hit (BVH.cpp:90-113) / BVH::has_hit (BVH.cpp:115-136) for n host rays.  origin/dir: 3 doubles per ray.
+ * t1,t2: per-ray interval.  Outputs (closest): t (fp32), triangle index in face order (-1 = miss), barycentric
+ * u,v.  any_hit != 0: out_tri[i] = 1/0 only. */
+mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir,
+                             const double* t1, const double* t2, int any_hit,
+                             float* out_t, int32_t* out_tri, float* out_u, float* out_v);
+/* Render::cast_Ray (Render.cpp:71-80) for n (x,y) pixels with the xi the caller supplies (2 per ray). */
+mcpt_status mcpt_probe_cast_ray(mcpt_ctx* ctx, uint32_t n, const int32_t* xy, const float* xi, float* out_origin_dir6);
+/* BSDF (BSDF.cpp:87-202) on synthetic hits: per item normal[3], wi[3], kd[3], ks[3], ns, wo[3] (world) and 3 xi
+ * {lobe, xi1, xi2}.  out per item: Fx(wo)[3], Pdf(wo), sample.wo[3], sample.f[3], sample.pdf, isMirror = 12 floats */
+mcpt_status mcpt_probe_bsdf(mcpt_ctx* ctx, uint32_t n, const float* normal, const float* wi, const float* kd,
+                            const float* ks, const float* ns, const float* wo, const float* xi, float* out12);
+/* Render::sample (Render.cpp:202-223) from n shading points (3 doubles each) with 3 xi each.
+ * out per item: wo[3], radiance[3], pdf, t2, light triangle index (as float), self_hit (0/1; the fp64 predicate
+ * of SURVEY A-9 evaluated on the sampled triangle only) = 10 floats */
+mcpt_status mcpt_probe_sample_light(mcpt_ctx* ctx, uint32_t n, const double* point, const float* xi, float* out10);
+/* One full path per item through the shipping integrator from a given ray, random numbers from the counter-based
+ * generator keyed (seed, pixel = item, sample = 0).  out: L[3]. */
+mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, uint64_t seed, float* out_L3);
+/* The generator itself: n*4 uniforms for (pixel, sample, block) triples -- pins oracle and device to one stream. */
+mcpt_status mcpt_probe_rng(mcpt_ctx* ctx, uint32_t n, const uint32_t* pixel_sample_block3, uint64_t seed, float* out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCPT_H */
