@@ -1,0 +1,83 @@
+// HBM layout of a scene, shared by the host (upload) and the gfx950 kernels.  See DESIGN.md §Data layout.
+//
+// The reference keeps a pointer-linked BVH of heap nodes over shared_ptr<Triangle> (BVH.h:11-20, 88 B/node +
+// 256 B AoS triangles, Triangle.h:11-14).  Here everything is a flat, index-linked array, split into a HOT
+// stream touched by traversal and COLD streams touched once per shaded hit ("structure of streams"; a
+// per-component x[] y[] z[] split would turn each gather into 3x more cache lines, so inside a stream the
+// record of one node / triangle is contiguous and 16-B aligned for global_load_dwordx4):
+//
+//   nodes      64 B / inner node : the TWO CHILD boxes + two child links  (one fetch -> two slab tests)
+//                f4[0] = c0.lo.x c0.hi.x c0.lo.y c0.hi.y
+//                f4[1] = c1.lo.x c1.hi.x c1.lo.y c1.hi.y
+//                f4[2] = c0.lo.z c0.hi.z c1.lo.z c1.hi.z
+//                f4[3] = (int) child0, child1, 0, 0     child >= 0: inner node index; child < 0: leaf, ~child =
+//                                                         first_triangle << 3 | count  (count <= 7, leaf order)
+//   tri_isect  48 B / triangle   : v0.xyz,_ | e1.xyz,_ | e2.xyz,_   (fp32; e = float(v_k - v_0) like Triangle.cpp:25-26)
+//   tri_shade  64 B / triangle   : n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y material
+//   tri_pos64  72 B / triangle   : v0 v1 v2 in fp64 -- read once per shaded hit to form the fp64 hit point the
+//                                  reference's shadow-ray self-occlusion depends on (SURVEY A-9), and per light sample
+//   tri_face    4 B / triangle   : leaf order -> face index of the input (Model::face order)
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define MCPT_LEAF_MAX 4
+#define MCPT_STACK_DEPTH 32        // LDS traversal stack entries per lane (BVH builder guarantees depth <= this)
+#define MCPT_BLOCK 256             // threads per workgroup = 4 waves of 64
+#define MCPT_NODE_SENTINEL ((int)0x80000000)
+
+struct DevMaterial {               // Material (model.h:32-40) + its Texture header (model.h:21-30)
+    float ks[3]; float ns;
+    float radiance[3]; uint32_t flags;       // MAT_*
+    int32_t tex_off, tex_w, tex_h, pad;      // texel offset into DevScene::texels (float4 per texel)
+};
+#define MAT_HAS_SPEC   1u   // glm::length(Ks) != 0                (BSDF.cpp:96)
+#define MAT_MIRROR     2u   // ... and Ns >= 10000                 (BSDF.cpp:98)
+#define MAT_EMISSIVE   4u   // glm::length(radiance) != 0          (Triangle.cpp:75, Render.cpp:146)
+#define MAT_EMIT_0     8u   // glm::length(radiance) > 0.0001      (Render.cpp:121)
+#define MAT_EMIT_REC  16u   // glm::length(radiance) > 0.01        (Render.cpp:94, light list :41)
+
+struct DevLight {                  // one entry of Render::lights (Render.cpp:41-42)
+    int32_t tri;                   // leaf-order triangle index
+    float area;                    // Triangle::area() (Triangle.cpp:24-28), fp32
+    float radiance[3];
+    float n0[3], n1[3], n2[3];     // vertex normals (fp32) for interplote_Normal
+    int32_t pad;
+};
+
+struct DevCamera {                 // Render::cast_Ray's per-frame constants hoisted (Render.cpp:73-75), fp64
+    double eye[3], front[3], right[3], up[3];
+    double h;                      // 2*tan(fovy/2)
+    int32_t width, height;
+};
+
+struct DevScene {
+    const float4* nodes;
+    const float4* tri_isect;
+    const float4* tri_shade;
+    const double* tri_pos64;
+    const int32_t* tri_face;
+    const DevMaterial* mats;
+    const DevLight* lights;
+    const float4* texels;
+    DevCamera cam;
+    int32_t n_tris, n_lights, n_nodes, n_mats;
+};
+
+struct RenderParams {
+    uint32_t spp;                  // samples per pixel in this launch
+    uint32_t first_sample;
+    uint32_t samples_per_item;     // samples one lane traces back-to-back
+    uint32_t chunks;               // ceil(spp / samples_per_item)
+    uint32_t tiles_x, tiles_y;     // 8x8 pixel tiles
+    uint32_t max_depth;            // 0 = unbounded
+    uint32_t flags;                // MCPT_FLAG_*
+    uint32_t integrator;
+    uint32_t seed_lo, seed_hi;
+    uint32_t atomic_accum;         // 1: several items per pixel -> float atomics; 0: plain read-modify-write
+};
+
+struct DevCounters {               // mirrors the integer part of mcpt_counters
+    unsigned long long paths, rays_primary, rays_continuation, rays_shadow, box_tests, tri_tests, shaded_hits,
+        texel_fetches, self_shadow_tests, self_shadow_hits;
+};

@@ -1,0 +1,368 @@
+// C ABI of libmcpt_hip.so (include/mcpt.h): context management, HBM upload, kernel launches.
+// No CPU path exists in this file: every compute entry point launches a gfx950 kernel or fails.
+#include "../../include/mcpt.h"
+#include "kernels.h"
+#include "scene_build.h"
+
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t alloc(size_t n) { bytes = n; return hipMalloc(&p, n ? n : 16); }
+    void free_() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+}  // namespace
+
+struct mcpt_ctx {
+    int device = 0;
+    mcpt_opts opts{};
+    DevScene dev{};
+    DevBuf nodes, tri_isect, tri_shade, tri_pos64, tri_face, mats, lights, texels, accum_own, counters;
+    float4* accum = nullptr;           // bound accumulator (own or external)
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_pending = false;
+    double last_kernel_ms = 0.0;
+    uint64_t launches = 0;
+    mcpt_scene_info info{};
+    int width = 0, height = 0;
+};
+
+namespace {
+
+mcpt_status fail(mcpt_status s, const std::string& msg) { g_err = msg; return s; }
+mcpt_status hip_fail(hipError_t e, const char* what) { g_err = std::string(what) + ": " + hipGetErrorString(e); return MCPT_ERR_HIP; }
+#define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+template <class T>
+hipError_t upload(DevBuf& b, const std::vector<T>& v) {
+    hipError_t e = b.alloc(v.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+void destroy_ctx(mcpt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->nodes.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_face.free_();
+    c->mats.free_(); c->lights.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+mcpt_status use(mcpt_ctx* c) {
+    if (!c) return fail(MCPT_ERR_INVALID_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return MCPT_OK;
+}
+
+// scratch device buffer for probes
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t in(const T* host, size_t n, T** dev) {
+        hipError_t e = hipMalloc((void**)dev, (n ? n : 1) * sizeof(T)); if (e != hipSuccess) return e;
+        ptrs.push_back(*dev);
+        return n ? hipMemcpy(*dev, host, n * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
+    }
+    template <class T> hipError_t out(size_t n, T** dev) {
+        hipError_t e = hipMalloc((void**)dev, (n ? n : 1) * sizeof(T)); if (e != hipSuccess) return e;
+        ptrs.push_back(*dev);
+        return hipMemset(*dev, 0, (n ? n : 1) * sizeof(T));
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+uint32_t mcpt_abi_version(void) { return MCPT_ABI_VERSION; }
+const char* mcpt_last_error(void) { return g_err.c_str(); }
+
+mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcpt_ctx** out_ctx) {
+    if (!scene || !out_ctx) return fail(MCPT_ERR_INVALID_ARG, "mcpt_create: null argument");
+    *out_ctx = nullptr;
+    mcpt_opts o; std::memset(&o, 0, sizeof o);
+    if (opts) std::memcpy(&o, opts, std::min<size_t>(sizeof o, opts->struct_size ? opts->struct_size : sizeof o));
+    if (o.integrator > MCPT_INTEGRATOR_RECURSIVE_NEE) return fail(MCPT_ERR_INVALID_ARG, "unknown integrator");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(MCPT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (o.device < 0 || o.device >= ndev) return fail(MCPT_ERR_NO_DEVICE, "device ordinal out of range");
+
+    HostScene hs; std::string err;
+    mcpt_status st = build_host_scene(scene, hs, err);
+    if (st != MCPT_OK) return fail(st, err);
+
+    mcpt_ctx* c = new mcpt_ctx();
+    c->device = o.device; c->opts = o; c->width = scene->camera.width; c->height = scene->camera.height;
+    auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };
+    if ((e = hipSetDevice(c->device)) != hipSuccess) return bail(e, "hipSetDevice");
+    auto t0 = std::chrono::steady_clock::now();
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    c->stream = c->own_stream;
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = upload(c->nodes, hs.nodes)) != hipSuccess) return bail(e, "upload nodes");
+    if ((e = upload(c->tri_isect, hs.tri_isect)) != hipSuccess) return bail(e, "upload tri_isect");
+    if ((e = upload(c->tri_shade, hs.tri_shade)) != hipSuccess) return bail(e, "upload tri_shade");
+    if ((e = upload(c->tri_pos64, hs.tri_pos64)) != hipSuccess) return bail(e, "upload tri_pos64");
+    if ((e = upload(c->tri_face, hs.tri_face)) != hipSuccess) return bail(e, "upload tri_face");
+    if ((e = upload(c->mats, hs.mats)) != hipSuccess) return bail(e, "upload materials");
+    if ((e = upload(c->lights, hs.lights)) != hipSuccess) return bail(e, "upload lights");
+    if ((e = upload(c->texels, hs.texels)) != hipSuccess) return bail(e, "upload texels");
+    const size_t accum_bytes = size_t(c->width) * c->height * sizeof(float4);
+    if ((e = c->accum_own.alloc(accum_bytes)) != hipSuccess) return bail(e, "alloc accumulator");
+    if ((e = hipMemset(c->accum_own.p, 0, accum_bytes)) != hipSuccess) return bail(e, "clear accumulator");
+    if ((e = c->counters.alloc(sizeof(DevCounters))) != hipSuccess) return bail(e, "alloc counters");
+    if ((e = hipMemset(c->counters.p, 0, sizeof(DevCounters))) != hipSuccess) return bail(e, "clear counters");
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "sync after upload");
+    c->accum = static_cast<float4*>(c->accum_own.p);
+
+    DevScene& d = c->dev;
+    d.nodes = static_cast<const float4*>(c->nodes.p); d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
+    d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p);
+    d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
+    d.lights = static_cast<const DevLight*>(c->lights.p); d.texels = static_cast<const float4*>(c->texels.p);
+    d.cam = hs.cam;
+    d.n_tris = int32_t(hs.tri_face.size()); d.n_lights = int32_t(hs.lights.size()); d.n_nodes = int32_t(hs.nodes.size() / 4); d.n_mats = int32_t(hs.mats.size());
+
+    mcpt_scene_info& in = c->info;
+    in.n_tris = uint32_t(d.n_tris); in.n_lights = uint32_t(d.n_lights); in.n_nodes = uint32_t(d.n_nodes);
+    in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
+    in.device_bytes = c->nodes.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_face.bytes + c->mats.bytes +
+                      c->lights.bytes + c->texels.bytes + accum_bytes;
+    in.bvh_build_ms = hs.bvh_build_ms;
+    in.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out_ctx = c;
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_destroy(mcpt_ctx* ctx) {
+    if (!ctx) return MCPT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    destroy_ctx(ctx);
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_get_scene_info(const mcpt_ctx* ctx, mcpt_scene_info* out) {
+    if (!ctx || !out) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    *out = ctx->info;
+    return MCPT_OK;
+}
+
+static mcpt_status resolve_timing(mcpt_ctx* c) {
+    if (c->timing_pending) {
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->last_kernel_ms = ms; c->timing_pending = false;
+    }
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t first_sample) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (spp == 0) return MCPT_OK;
+    st = resolve_timing(ctx); if (st != MCPT_OK) return st;
+    RenderParams p; std::memset(&p, 0, sizeof p);
+    p.spp = spp; p.first_sample = first_sample;
+    p.tiles_x = uint32_t((ctx->width + 7) / 8); p.tiles_y = uint32_t((ctx->height + 7) / 8);
+    const uint64_t tiles = uint64_t(p.tiles_x) * p.tiles_y;
+    uint32_t spi = ctx->opts.samples_per_item;
+    if (ctx->opts.flags & MCPT_FLAG_DETERMINISTIC) spi = spp;               // one lane owns a pixel for the whole call
+    else if (spi == 0) {
+        // auto: long enough that the end-of-item tail (lanes idling while the slowest lane of the wave finishes) is small,
+        // short enough that there are >= ~16 waves per SIMD slot to balance across the chip (256 CUs x 16 waves)
+        spi = 64;
+        while (spi > 8 && tiles * ((spp + spi - 1) / spi) < 256ull * 16 * 16) spi >>= 1;
+        if (spi > spp) spi = spp;
+    }
+    if (spi > spp) spi = spp;
+    p.samples_per_item = spi; p.chunks = (spp + spi - 1) / spi;
+    p.atomic_accum = p.chunks > 1 ? 1u : 0u;
+    p.max_depth = ctx->opts.max_depth; p.flags = ctx->opts.flags; p.integrator = ctx->opts.integrator;
+    p.seed_lo = uint32_t(seed); p.seed_hi = uint32_t(seed >> 32);
+    if (tiles * p.chunks > 0x3fffffffull) return fail(MCPT_ERR_UNSUPPORTED, "launch too large: lower spp per call or raise samples_per_item");
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(launch_render(ctx->dev, p, ctx->accum, static_cast<DevCounters*>(ctx->counters.p), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timing_pending = true; ctx->launches++;
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_sync(mcpt_ctx* ctx) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return resolve_timing(ctx);
+}
+
+mcpt_status mcpt_read_accum(mcpt_ctx* ctx, float* rgba_host) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!rgba_host) return fail(MCPT_ERR_INVALID_ARG, "null output");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(rgba_host, ctx->accum, size_t(ctx->width) * ctx->height * sizeof(float4), hipMemcpyDeviceToHost));
+    return resolve_timing(ctx);
+}
+mcpt_status mcpt_write_accum(mcpt_ctx* ctx, const float* rgba_host) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!rgba_host) return fail(MCPT_ERR_INVALID_ARG, "null input");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ctx->accum, rgba_host, size_t(ctx->width) * ctx->height * sizeof(float4), hipMemcpyHostToDevice));
+    return MCPT_OK;
+}
+mcpt_status mcpt_clear_accum(mcpt_ctx* ctx) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    HIP_TRY(hipMemsetAsync(ctx->accum, 0, size_t(ctx->width) * ctx->height * sizeof(float4), ctx->stream));
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_tonemap(mcpt_ctx* ctx, uint8_t* rgb_host, int flip_y) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!rgb_host) return fail(MCPT_ERR_INVALID_ARG, "null output");
+    const size_t n = size_t(ctx->width) * ctx->height;
+    Scratch s; uint8_t* d_rgb = nullptr;
+    HIP_TRY(s.out(3 * n, &d_rgb));
+    HIP_TRY(launch_tonemap(ctx->accum, d_rgb, ctx->width, ctx->height, flip_y, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(rgb_host, d_rgb, 3 * n, hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_get_counters(mcpt_ctx* ctx, mcpt_counters* out) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!out) return fail(MCPT_ERR_INVALID_ARG, "null output");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    st = resolve_timing(ctx); if (st != MCPT_OK) return st;
+    DevCounters d;
+    HIP_TRY(hipMemcpy(&d, ctx->counters.p, sizeof d, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->paths = d.paths; out->rays_primary = d.rays_primary; out->rays_continuation = d.rays_continuation; out->rays_shadow = d.rays_shadow;
+    out->box_tests = d.box_tests; out->tri_tests = d.tri_tests; out->shaded_hits = d.shaded_hits; out->texel_fetches = d.texel_fetches;
+    out->self_shadow_tests = d.self_shadow_tests; out->self_shadow_hits = d.self_shadow_hits;
+    out->kernel_ms = ctx->last_kernel_ms; out->launches = ctx->launches;
+    return MCPT_OK;
+}
+mcpt_status mcpt_reset_counters(mcpt_ctx* ctx) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemset(ctx->counters.p, 0, sizeof(DevCounters)));
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_bind_accum(mcpt_ctx* ctx, void* device_rgba) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->accum = device_rgba ? static_cast<float4*>(device_rgba) : static_cast<float4*>(ctx->accum_own.p);
+    return MCPT_OK;
+}
+mcpt_status mcpt_accum_device_ptr(mcpt_ctx* ctx, void** out_device_rgba) {
+    if (!ctx || !out_device_rgba) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    *out_device_rgba = ctx->accum;
+    return MCPT_OK;
+}
+mcpt_status mcpt_set_stream(mcpt_ctx* ctx, void* hip_stream) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    st = resolve_timing(ctx); if (st != MCPT_OK) return st;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return MCPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ probes
+mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, const double* t1, const double* t2, int any_hit,
+                             float* out_t, int32_t* out_tri, float* out_u, float* out_v) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!origin || !dir || !t1 || !t2 || !out_t || !out_tri || !out_u || !out_v) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MCPT_OK;
+    Scratch s; double *d_o, *d_d, *d_t1, *d_t2; float *d_t, *d_u, *d_v; int* d_tri;
+    HIP_TRY(s.in(origin, 3 * size_t(n), &d_o)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.in(t1, n, &d_t1)); HIP_TRY(s.in(t2, n, &d_t2));
+    HIP_TRY(s.out(n, &d_t)); HIP_TRY(s.out(n, &d_tri)); HIP_TRY(s.out(n, &d_u)); HIP_TRY(s.out(n, &d_v));
+    HIP_TRY(launch_probe_trace(ctx->dev, n, d_o, d_d, d_t1, d_t2, any_hit, d_t, d_tri, d_u, d_v, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(out_tri, d_tri, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_u, d_u, n * sizeof(float), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(out_v, d_v, n * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_probe_cast_ray(mcpt_ctx* ctx, uint32_t n, const int32_t* xy, const float* xi, float* out6) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!xy || !xi || !out6) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MCPT_OK;
+    Scratch s; int* d_xy; float *d_xi, *d_out;
+    HIP_TRY(s.in(xy, 2 * size_t(n), &d_xy)); HIP_TRY(s.in(xi, 2 * size_t(n), &d_xi)); HIP_TRY(s.out(6 * size_t(n), &d_out));
+    HIP_TRY(launch_probe_cast_ray(ctx->dev, n, d_xy, d_xi, d_out, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out6, d_out, 6 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_probe_bsdf(mcpt_ctx* ctx, uint32_t n, const float* normal, const float* wi, const float* kd, const float* ks, const float* ns,
+                            const float* wo, const float* xi, float* out12) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!normal || !wi || !kd || !ks || !ns || !wo || !xi || !out12) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MCPT_OK;
+    Scratch s; float *d_n, *d_wi, *d_kd, *d_ks, *d_ns, *d_wo, *d_xi, *d_out;
+    HIP_TRY(s.in(normal, 3 * size_t(n), &d_n)); HIP_TRY(s.in(wi, 3 * size_t(n), &d_wi)); HIP_TRY(s.in(kd, 3 * size_t(n), &d_kd));
+    HIP_TRY(s.in(ks, 3 * size_t(n), &d_ks)); HIP_TRY(s.in(ns, n, &d_ns)); HIP_TRY(s.in(wo, 3 * size_t(n), &d_wo)); HIP_TRY(s.in(xi, 3 * size_t(n), &d_xi));
+    HIP_TRY(s.out(12 * size_t(n), &d_out));
+    HIP_TRY(launch_probe_bsdf(n, d_n, d_wi, d_kd, d_ks, d_ns, d_wo, d_xi, d_out, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out12, d_out, 12 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_probe_sample_light(mcpt_ctx* ctx, uint32_t n, const double* point, const float* xi, float* out10) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!point || !xi || !out10) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MCPT_OK;
+    Scratch s; double* d_p; float *d_xi, *d_out;
+    HIP_TRY(s.in(point, 3 * size_t(n), &d_p)); HIP_TRY(s.in(xi, 3 * size_t(n), &d_xi)); HIP_TRY(s.out(10 * size_t(n), &d_out));
+    HIP_TRY(launch_probe_sample_light(ctx->dev, n, d_p, d_xi, d_out, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out10, d_out, 10 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, uint64_t seed, float* out_L3) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!origin || !dir || !out_L3) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MCPT_OK;
+    if (ctx->opts.integrator != MCPT_INTEGRATOR_MIS) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_paths drives the MIS integrator only");
+    Scratch s; double *d_o, *d_d; float* d_out; DevCounters* d_cnt;
+    HIP_TRY(s.in(origin, 3 * size_t(n), &d_o)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.out(3 * size_t(n), &d_out)); HIP_TRY(s.out(1, &d_cnt));
+    RenderParams p; std::memset(&p, 0, sizeof p);
+    p.spp = 1; p.first_sample = 0; p.samples_per_item = 1; p.chunks = 1; p.tiles_x = 0x7fffffffu; p.tiles_y = 1;
+    p.max_depth = ctx->opts.max_depth; p.flags = ctx->opts.flags & ~MCPT_FLAG_COUNT_TRAVERSAL; p.integrator = MCPT_INTEGRATOR_MIS;
+    p.seed_lo = uint32_t(seed); p.seed_hi = uint32_t(seed >> 32);
+    HIP_TRY(launch_probe_paths(ctx->dev, p, n, d_o, d_d, d_out, d_cnt, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out_L3, d_out, 3 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+mcpt_status mcpt_probe_rng(mcpt_ctx* ctx, uint32_t n, const uint32_t* key3, uint64_t seed, float* out4) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!key3 || !out4) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MCPT_OK;
+    Scratch s; uint32_t* d_k; float* d_out;
+    HIP_TRY(s.in(key3, 3 * size_t(n), &d_k)); HIP_TRY(s.out(4 * size_t(n), &d_out));
+    HIP_TRY(launch_probe_rng(n, d_k, uint32_t(seed), uint32_t(seed >> 32), d_out, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out4, d_out, 4 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+}  // extern "C"

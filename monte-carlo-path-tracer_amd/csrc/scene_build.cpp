@@ -1,0 +1,266 @@
+// Host-side scene preparation (see scene_build.h).
+//
+//  * flatten():  Render::tranform_triangle (Render.cpp:12-44) -- faces -> triangles by index, material per face
+//                from corner 0, lights = triangles whose |radiance| > 0.01 in face order.
+//  * Builder:    replaces BVH::build (BVH.cpp:15-54: spatial-midpoint split of the centroid box, leaf <= 5,
+//                pointer tree).  The traversal result (closest hit / any hit) does not depend on the tree, only its
+//                cost does, so the tree here is built for the GPU: binned-SAH splits (16 bins x 3 axes), leaves
+//                <= MCPT_LEAF_MAX triangles, child boxes stored in the parent (64-B nodes), depth capped so the LDS
+//                stack of MCPT_STACK_DEPTH entries can never overflow (median splits take over when the remaining
+//                depth budget gets tight).  Boxes are the fp64 triangle bounds rounded OUTWARD to fp32 and padded by
+//                ~16 ulp so the fp32 slab test never rejects a box whose fp32 triangle test would accept.
+#include "scene_build.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace {
+
+struct BTri { double lo[3], hi[3], c[3]; };
+struct Box {
+    double lo[3], hi[3];
+    Box() { for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<double>::max(); hi[a] = std::numeric_limits<double>::lowest(); } }
+    void grow(const double* l, const double* h) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); } }
+    void grow(const Box& b) { grow(b.lo, b.hi); }
+    void grow_pt(const double* p) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    double area() const {
+        double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0;
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+inline int leaf_code(uint32_t first, uint32_t count) { return ~int((first << 3) | count); }
+inline float as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
+
+inline float round_down(double v, float pad) { float f = float(v); if (double(f) > v) f = std::nextafterf(f, -INFINITY); return f - pad; }
+inline float round_up(double v, float pad) { float f = float(v); if (double(f) < v) f = std::nextafterf(f, INFINITY); return f + pad; }
+
+class Builder {
+public:
+    Builder(const std::vector<BTri>& t, std::vector<f4h>& nodes) : t_(t), nodes_(nodes), order_(t.size()) {
+        for (size_t i = 0; i < order_.size(); i++) order_[i] = int(i);
+    }
+    void run() {
+        const int n = int(t_.size());
+        Box rb;
+        if (n <= MCPT_LEAF_MAX) {            // keep the invariant "node 0 is an inner node"
+            nodes_.resize(4);
+            Box b; for (int i = 0; i < n; i++) b.grow(t_[i].lo, t_[i].hi);
+            Box empty; for (int a = 0; a < 3; a++) { empty.lo[a] = 0; empty.hi[a] = 0; }
+            write_node(0, b, leaf_code(0, uint32_t(n)), empty, leaf_code(0, 0));
+            max_leaf = uint32_t(n); depth = 1;
+            return;
+        }
+        build(0, n, 0, rb);
+    }
+    const std::vector<int>& order() const { return order_; }
+    uint32_t depth = 0, max_leaf = 0;
+
+private:
+    static constexpr int kBins = 16;
+    static constexpr int kMaxDepth = MCPT_STACK_DEPTH - 2;   // inner-node levels; stack holds sentinel + one entry per level
+
+    static int levels_needed(int n) { int l = 0; while ((MCPT_LEAF_MAX << l) < n) l++; return l; }
+
+    void write_node(int idx, const Box& b0, int c0, const Box& b1, int c1) {
+        auto pad_of = [](const Box& b) {
+            double m = 0; for (int a = 0; a < 3; a++) m = std::max(m, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+            return float(m * 1e-6 + 1e-30);
+        };
+        const float p0 = pad_of(b0), p1 = pad_of(b1);
+        f4h* n = &nodes_[4 * size_t(idx)];
+        n[0] = {round_down(b0.lo[0], p0), round_up(b0.hi[0], p0), round_down(b0.lo[1], p0), round_up(b0.hi[1], p0)};
+        n[1] = {round_down(b1.lo[0], p1), round_up(b1.hi[0], p1), round_down(b1.lo[1], p1), round_up(b1.hi[1], p1)};
+        n[2] = {round_down(b0.lo[2], p0), round_up(b0.hi[2], p0), round_down(b1.lo[2], p1), round_up(b1.hi[2], p1)};
+        n[3] = {as_float(c0), as_float(c1), 0.f, 0.f};
+    }
+
+    // returns child code (inner index >= 0 or leaf code < 0); `box` = bounds of [l,r)
+    int build(int l, int r, int d, Box& box) {
+        const int n = r - l;
+        for (int i = l; i < r; i++) box.grow(t_[order_[i]].lo, t_[order_[i]].hi);
+        if (n <= MCPT_LEAF_MAX) {
+            max_leaf = std::max(max_leaf, uint32_t(n));
+            return leaf_code(uint32_t(l), uint32_t(n));
+        }
+        depth = std::max(depth, uint32_t(d + 1));
+        Box cb;
+        for (int i = l; i < r; i++) cb.grow_pt(t_[order_[i]].c);
+        int mid = -1;
+        const int budget = kMaxDepth - (d + 1);               // levels left for each child
+        // ---- binned SAH over the three axes
+        double best_cost = std::numeric_limits<double>::max(); int best_axis = -1, best_bin = -1;
+        for (int a = 0; a < 3; a++) {
+            const double ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0)) continue;
+            Box bb[kBins]; int cnt[kBins] = {0};
+            const double scale = kBins / ext;
+            for (int i = l; i < r; i++) {
+                const BTri& T = t_[order_[i]];
+                int b = int((T.c[a] - cb.lo[a]) * scale); b = std::min(std::max(b, 0), kBins - 1);
+                bb[b].grow(T.lo, T.hi); cnt[b]++;
+            }
+            double la[kBins], ra[kBins]; int lc[kBins], rc[kBins];
+            Box acc; int c = 0;
+            for (int b = 0; b < kBins; b++) { acc.grow(bb[b]); c += cnt[b]; la[b] = acc.area(); lc[b] = c; }
+            Box acc2; c = 0;
+            for (int b = kBins - 1; b >= 0; b--) { acc2.grow(bb[b]); c += cnt[b]; ra[b] = acc2.area(); rc[b] = c; }
+            for (int b = 0; b < kBins - 1; b++) {
+                if (lc[b] == 0 || rc[b + 1] == 0) continue;
+                if (levels_needed(lc[b]) > budget || levels_needed(rc[b + 1]) > budget) continue;
+                const double cost = la[b] * lc[b] + ra[b + 1] * rc[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const double scale = kBins / (cb.hi[a] - cb.lo[a]);
+            auto it = std::partition(order_.begin() + l, order_.begin() + r, [&](int ti) {
+                int b = int((t_[ti].c[a] - cb.lo[a]) * scale); b = std::min(std::max(b, 0), kBins - 1);
+                return b <= best_bin;
+            });
+            mid = int(it - order_.begin());
+        }
+        if (mid <= l || mid >= r) {                            // degenerate or out of depth budget: object median
+            int a = 0; double ext = cb.hi[0] - cb.lo[0];
+            for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > ext) { ext = cb.hi[k] - cb.lo[k]; a = k; }
+            mid = l + n / 2;
+            std::nth_element(order_.begin() + l, order_.begin() + mid, order_.begin() + r,
+                             [&](int x, int y) { return t_[x].c[a] < t_[y].c[a]; });
+        }
+        const int idx = int(nodes_.size() / 4);
+        nodes_.resize(nodes_.size() + 4);
+        Box b0, b1;
+        const int c0 = build(l, mid, d + 1, b0);
+        const int c1 = build(mid, r, d + 1, b1);
+        write_node(idx, b0, c0, b1, c1);
+        return idx;
+    }
+
+    const std::vector<BTri>& t_;
+    std::vector<f4h>& nodes_;
+    std::vector<int> order_;
+};
+
+inline double len3(const double* v) { return std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+
+}  // namespace
+
+mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err) {
+    if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
+    if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }
+    if (d->camera.width <= 0 || d->camera.height <= 0) { err = "camera width/height must be positive"; return MCPT_ERR_INVALID_ARG; }
+    if (d->n_face >= (1u << 28)) { err = "too many faces (limit 2^28-1)"; return MCPT_ERR_UNSUPPORTED; }
+    const uint32_t nf = d->n_face;
+
+    // ---- materials + textures
+    out.texels.clear(); out.mats.clear();
+    std::vector<int32_t> tex_off(d->n_textures);
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const mcpt_texture& t = d->textures[i];
+        if (t.width <= 0 || t.height <= 0 || !t.rgb) { err = "bad texture " + std::to_string(i); return MCPT_ERR_INVALID_ARG; }
+        tex_off[i] = int32_t(out.texels.size());
+        const size_t n = size_t(t.width) * t.height;
+        for (size_t k = 0; k < n; k++) out.texels.push_back({t.rgb[3 * k], t.rgb[3 * k + 1], t.rgb[3 * k + 2], 0.f});
+    }
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const mcpt_material& m = d->materials[i];
+        if (m.map_kd < 0 || uint32_t(m.map_kd) >= d->n_textures) { err = "material " + std::to_string(i) + ": map_kd out of range (the reference dereferences a null Map_Kd here)"; return MCPT_ERR_INVALID_ARG; }
+        DevMaterial dm; std::memset(&dm, 0, sizeof dm);
+        for (int k = 0; k < 3; k++) { dm.ks[k] = float(m.ks[k]); dm.radiance[k] = float(m.radiance[k]); }
+        dm.ns = float(m.ns);
+        if (len3(m.ks) != 0.0) { dm.flags |= MAT_HAS_SPEC; if (m.ns >= 10000) dm.flags |= MAT_MIRROR; }   // BSDF.cpp:96-98
+        const double rl = len3(m.radiance);
+        if (rl != 0.0) dm.flags |= MAT_EMISSIVE;
+        if (rl > 0.0001) dm.flags |= MAT_EMIT_0;
+        if (rl > 0.01) dm.flags |= MAT_EMIT_REC;
+        dm.tex_off = tex_off[m.map_kd]; dm.tex_w = d->textures[m.map_kd].width; dm.tex_h = d->textures[m.map_kd].height;
+        out.mats.push_back(dm);
+    }
+
+    // ---- flatten faces (Render.cpp:12-44)
+    std::vector<BTri> bt(nf);
+    for (uint32_t f = 0; f < nf; f++) {
+        const int32_t* c = d->face + 12 * size_t(f);
+        for (int k = 0; k < 3; k++) {
+            if (c[4 * k] < 0 || uint32_t(c[4 * k]) >= d->n_vertex || c[4 * k + 1] < 0 || uint32_t(c[4 * k + 1]) >= d->n_normal ||
+                c[4 * k + 2] < 0 || uint32_t(c[4 * k + 2]) >= d->n_texcoord) { err = "face " + std::to_string(f) + ": index out of range"; return MCPT_ERR_INVALID_ARG; }
+        }
+        if (c[3] < 0 || uint32_t(c[3]) >= d->n_materials) { err = "face " + std::to_string(f) + ": material out of range"; return MCPT_ERR_INVALID_ARG; }
+        BTri& T = bt[f];
+        for (int a = 0; a < 3; a++) {
+            const double x0 = d->vertex[3 * c[0] + a], x1 = d->vertex[3 * c[4] + a], x2 = d->vertex[3 * c[8] + a];
+            T.lo[a] = std::min(x0, std::min(x1, x2)); T.hi[a] = std::max(x0, std::max(x1, x2));
+            T.c[a] = (x0 + x1 + x2) / 3.0;
+        }
+    }
+
+    // ---- BVH
+    auto t0 = std::chrono::steady_clock::now();
+    out.nodes.clear();
+    Builder b(bt, out.nodes);
+    b.run();
+    out.bvh_depth = b.depth; out.max_leaf = b.max_leaf;
+    out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (out.bvh_depth > uint32_t(MCPT_STACK_DEPTH - 1)) { err = "BVH depth exceeds traversal stack"; return MCPT_ERR_BVH_DEPTH; }
+    const std::vector<int>& order = b.order();
+    std::vector<int> pos_of_face(nf);
+    for (uint32_t i = 0; i < nf; i++) pos_of_face[order[i]] = int(i);
+
+    // ---- streams in leaf order
+    out.tri_isect.resize(3 * size_t(nf)); out.tri_shade.resize(4 * size_t(nf)); out.tri_pos64.resize(9 * size_t(nf)); out.tri_face.resize(nf);
+    for (uint32_t i = 0; i < nf; i++) {
+        const int f = order[i];
+        const int32_t* c = d->face + 12 * size_t(f);
+        const double* v0 = d->vertex + 3 * c[0]; const double* v1 = d->vertex + 3 * c[4]; const double* v2 = d->vertex + 3 * c[8];
+        const double* n0 = d->normal + 3 * c[1]; const double* n1 = d->normal + 3 * c[5]; const double* n2 = d->normal + 3 * c[9];
+        const double* t0_ = d->texcoord + 2 * c[2]; const double* t1_ = d->texcoord + 2 * c[6]; const double* t2_ = d->texcoord + 2 * c[10];
+        out.tri_isect[3 * size_t(i) + 0] = {float(v0[0]), float(v0[1]), float(v0[2]), 0.f};
+        out.tri_isect[3 * size_t(i) + 1] = {float(v1[0] - v0[0]), float(v1[1] - v0[1]), float(v1[2] - v0[2]), 0.f};
+        out.tri_isect[3 * size_t(i) + 2] = {float(v2[0] - v0[0]), float(v2[1] - v0[1]), float(v2[2] - v0[2]), 0.f};
+        out.tri_shade[4 * size_t(i) + 0] = {float(n0[0]), float(n0[1]), float(n0[2]), float(t0_[0])};
+        out.tri_shade[4 * size_t(i) + 1] = {float(n1[0]), float(n1[1]), float(n1[2]), float(t0_[1])};
+        out.tri_shade[4 * size_t(i) + 2] = {float(n2[0]), float(n2[1]), float(n2[2]), float(t1_[0])};
+        out.tri_shade[4 * size_t(i) + 3] = {float(t1_[1]), float(t2_[0]), float(t2_[1]), as_float(c[3])};
+        for (int a = 0; a < 3; a++) { out.tri_pos64[9 * size_t(i) + a] = v0[a]; out.tri_pos64[9 * size_t(i) + 3 + a] = v1[a]; out.tri_pos64[9 * size_t(i) + 6 + a] = v2[a]; }
+        out.tri_face[i] = f;
+    }
+
+    // ---- lights in face order (Render.cpp:41-42)
+    out.lights.clear();
+    for (uint32_t f = 0; f < nf; f++) {
+        const int32_t* c = d->face + 12 * size_t(f);
+        const mcpt_material& m = d->materials[c[3]];
+        if (!(len3(m.radiance) > 0.01)) continue;
+        DevLight L; std::memset(&L, 0, sizeof L);
+        L.tri = pos_of_face[f];
+        const f4h e1 = out.tri_isect[3 * size_t(L.tri) + 1], e2 = out.tri_isect[3 * size_t(L.tri) + 2];
+        const float cx = e1.y * e2.z - e2.y * e1.z, cy = e1.z * e2.x - e2.z * e1.x, cz = e1.x * e2.y - e2.x * e1.y;
+        L.area = 0.5f * std::sqrt((cx * cx + cy * cy) + cz * cz);                       // Triangle.cpp:24-28
+        for (int a = 0; a < 3; a++) {
+            L.radiance[a] = float(m.radiance[a]);
+            L.n0[a] = float(d->normal[3 * c[1] + a]); L.n1[a] = float(d->normal[3 * c[5] + a]); L.n2[a] = float(d->normal[3 * c[9] + a]);
+        }
+        out.lights.push_back(L);
+    }
+    if (out.lights.empty()) { err = "scene has no emissive triangle (|radiance| > 0.01); the reference indexes lights[-1] here"; return MCPT_ERR_NO_LIGHTS; }
+
+    // ---- camera constants (Render.cpp:73-75), fp64, glm operation order
+    const mcpt_camera& cm = d->camera;
+    DevCamera& cam = out.cam;
+    const double PI_D = 3.14159265358979323846;
+    cam.h = std::tan(cm.fovy * PI_D / 180.0 * 0.5) * 2.0;
+    double fr[3] = {cm.lookat[0] - cm.eye[0], cm.lookat[1] - cm.eye[1], cm.lookat[2] - cm.eye[2]};
+    double inv = 1.0 / len3(fr);
+    for (int a = 0; a < 3; a++) { cam.front[a] = fr[a] * inv; cam.eye[a] = cm.eye[a]; cam.up[a] = cm.up[a]; }
+    double rt[3] = {cam.front[1] * cm.up[2] - cm.up[1] * cam.front[2], cam.front[2] * cm.up[0] - cm.up[2] * cam.front[0],
+                    cam.front[0] * cm.up[1] - cm.up[0] * cam.front[1]};
+    inv = 1.0 / len3(rt);
+    for (int a = 0; a < 3; a++) cam.right[a] = rt[a] * inv;
+    cam.width = cm.width; cam.height = cm.height;
+    return MCPT_OK;
+}

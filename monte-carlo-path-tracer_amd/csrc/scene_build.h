@@ -1,0 +1,28 @@
+// Host-side scene preparation: the MI355X replacement for Render::tranform_triangle (Render.cpp:12-44) and
+// BVH::BVH / BVH::build (BVH.cpp:6-54).  Output = the flat arrays of device_scene.h, ready for one hipMemcpy each.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/mcpt.h"
+#include "device_scene.h"
+
+struct f4h { float x, y, z, w; };   // host mirror of float4 (16 B)
+
+struct HostScene {
+    std::vector<f4h> nodes;          // 4 per inner node
+    std::vector<f4h> tri_isect;      // 3 per triangle (leaf order)
+    std::vector<f4h> tri_shade;      // 4 per triangle
+    std::vector<double> tri_pos64;   // 9 per triangle
+    std::vector<int32_t> tri_face;   // leaf order -> input face index
+    std::vector<DevMaterial> mats;
+    std::vector<DevLight> lights;
+    std::vector<f4h> texels;
+    DevCamera cam;
+    uint32_t bvh_depth = 0, max_leaf = 0;
+    double bvh_build_ms = 0.0;
+};
+
+// Validates the description (indices in range, sizes non-zero), flattens faces, collects lights, builds the BVH.
+// Returns MCPT_OK or an error code with `err` filled.
+mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err);
