@@ -102,8 +102,9 @@ typedef struct mcpt_counters {
     uint64_t texel_fetches;     /* image-texture lookups  (only with COUNT_TRAVERSAL) */
     uint64_t self_shadow_tests; /* light samples that reached the fp64 self-hit predicate (A-9) */
     uint64_t self_shadow_hits;  /* ... and were rejected by it */
-    double   kernel_ms;         /* HIP-event time of the render kernels of the LAST mcpt_render call */
-    uint64_t launches;          /* render kernel launches so far */
+    double   kernel_ms;         /* HIP-event duration of the render kernel of the LAST mcpt_render call */
+    double   kernel_ms_total;   /* sum of those durations over all mcpt_render calls since the last reset */
+    uint64_t launches;          /* mcpt_render launches since the last reset */
 } mcpt_counters;
 
 typedef struct mcpt_scene_info {

@@ -64,7 +64,7 @@ class Counters(C.Structure):
                 ("rays_shadow", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("shaded_hits", C.c_uint64), ("texel_fetches", C.c_uint64),
                 ("self_shadow_tests", C.c_uint64), ("self_shadow_hits", C.c_uint64),
-                ("kernel_ms", C.c_double), ("launches", C.c_uint64)]
+                ("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("launches", C.c_uint64)]
 
     @property
     def rays(self) -> int:
@@ -136,10 +136,11 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MCPT_LIB_PATH", LIB_PATH)     # developer override: A/B another build of the same ABI
+    if not os.path.exists(path):
         raise RuntimeError("libmcpt_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "or `make -C monte-carlo-path-tracer_amd/csrc`.  No CPU fallback exists." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                           "or `make -C monte-carlo-path-tracer_amd/csrc`.  No CPU fallback exists." % path)
+    lib = C.CDLL(path)
     P = C.POINTER
     vp = C.c_void_p
     sigs = {

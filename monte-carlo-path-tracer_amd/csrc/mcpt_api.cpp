@@ -30,7 +30,7 @@ struct mcpt_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_pending = false;
-    double last_kernel_ms = 0.0;
+    double last_kernel_ms = 0.0, total_kernel_ms = 0.0;
     uint64_t launches = 0;
     mcpt_scene_info info{};
     int width = 0, height = 0;
@@ -168,7 +168,7 @@ static mcpt_status resolve_timing(mcpt_ctx* c) {
         HIP_TRY(hipEventSynchronize(c->ev1));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->last_kernel_ms = ms; c->timing_pending = false;
+        c->last_kernel_ms = ms; c->total_kernel_ms += ms; c->timing_pending = false;
     }
     return MCPT_OK;
 }
@@ -252,13 +252,15 @@ mcpt_status mcpt_get_counters(mcpt_ctx* ctx, mcpt_counters* out) {
     out->paths = d.paths; out->rays_primary = d.rays_primary; out->rays_continuation = d.rays_continuation; out->rays_shadow = d.rays_shadow;
     out->box_tests = d.box_tests; out->tri_tests = d.tri_tests; out->shaded_hits = d.shaded_hits; out->texel_fetches = d.texel_fetches;
     out->self_shadow_tests = d.self_shadow_tests; out->self_shadow_hits = d.self_shadow_hits;
-    out->kernel_ms = ctx->last_kernel_ms; out->launches = ctx->launches;
+    out->kernel_ms = ctx->last_kernel_ms; out->kernel_ms_total = ctx->total_kernel_ms; out->launches = ctx->launches;
     return MCPT_OK;
 }
 mcpt_status mcpt_reset_counters(mcpt_ctx* ctx) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemset(ctx->counters.p, 0, sizeof(DevCounters)));
+    st = resolve_timing(ctx); if (st != MCPT_OK) return st;
+    ctx->total_kernel_ms = 0.0; ctx->launches = 0;
     return MCPT_OK;
 }
 
