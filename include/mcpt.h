@@ -102,9 +102,12 @@ typedef struct mcpt_counters {
     uint64_t texel_fetches;     /* image-texture lookups  (only with COUNT_TRAVERSAL) */
     uint64_t self_shadow_tests; /* light samples that reached the fp64 self-hit predicate (A-9) */
     uint64_t self_shadow_hits;  /* ... and were rejected by it */
-    double   kernel_ms;         /* HIP-event duration of the render kernel of the LAST mcpt_render call */
+    double   kernel_ms;         /* HIP-event duration of all render kernels of the LAST mcpt_render call */
     double   kernel_ms_total;   /* sum of those durations over all mcpt_render calls since the last reset */
-    uint64_t launches;          /* mcpt_render launches since the last reset */
+    uint64_t launches;          /* mcpt_render calls since the last reset */
+    double   trace_ms_total;    /* wavefront pipeline, detailed timing on: summed duration of the traversal kernel ... */
+    double   shade_ms_total;    /* ... and of the shade kernel since the last reset (0 when detailed timing is off) */
+    uint64_t iterations;        /* [shade, trace] iterations since the last reset (each is one launch of either kernel) */
 } mcpt_counters;
 
 typedef struct mcpt_scene_info {

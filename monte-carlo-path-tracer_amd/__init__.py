@@ -64,7 +64,8 @@ class Counters(C.Structure):
                 ("rays_shadow", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("shaded_hits", C.c_uint64), ("texel_fetches", C.c_uint64),
                 ("self_shadow_tests", C.c_uint64), ("self_shadow_hits", C.c_uint64),
-                ("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("launches", C.c_uint64)]
+                ("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("launches", C.c_uint64),
+                ("trace_ms_total", C.c_double), ("shade_ms_total", C.c_double), ("iterations", C.c_uint64)]
 
     @property
     def rays(self) -> int:

@@ -22,7 +22,9 @@
 #include <hip/hip_runtime.h>
 
 #define MCPT_LEAF_MAX 4
+#ifndef MCPT_STACK_DEPTH
 #define MCPT_STACK_DEPTH 32        // LDS traversal stack entries per lane (BVH builder guarantees depth <= this)
+#endif
 #define MCPT_BLOCK 256             // threads per workgroup = 4 waves of 64
 #define MCPT_NODE_SENTINEL ((int)0x80000000)
 

@@ -4,6 +4,10 @@
 #include "pt_device.h"
 #include "kernels.h"
 
+#ifndef MCPT_MIN_WAVES
+#define MCPT_MIN_WAVES 2      // waves per SIMD the register allocator must leave room for (launch_bounds 2nd arg)
+#endif
+
 // ======================================================================================================
 // Work decomposition.  One work item = (pixel, chunk of `samples_per_item` consecutive samples).  One LANE owns one
 // item and traces its samples back-to-back inside ONE flattened loop: the moment a lane's path ends it starts its
@@ -50,7 +54,7 @@ __device__ __forceinline__ f3 scrub_nan(f3 c) {          // Scene::set_Pixel (Sc
 // PROBE = true turns the same loop into mcpt_probe_paths: item i traces ONE path from the caller's ray (probe_o/probe_d),
 // random numbers keyed (pixel = i, sample = 0), radiance written to probe_out instead of the film.
 template <bool COUNT, bool PROBE>
-__global__ void __launch_bounds__(MCPT_BLOCK) render_mis_kernel(DevScene sc, RenderParams p, float4* __restrict__ accum, DevCounters* gcnt,
+__global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_mis_kernel(DevScene sc, RenderParams p, float4* __restrict__ accum, DevCounters* gcnt,
                                                                 const double* probe_o, const double* probe_d, float* probe_out, uint32_t probe_n) {
     __shared__ int s_stack[MCPT_STACK_DEPTH * MCPT_BLOCK];
     int* stk = s_stack + threadIdx.x;
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK) render_mis_kernel(DevScene sc, Ren
 //   L_k + f_k |n.wo| / pdf_k * (next level)          becomes   total += T_k * L_k,  T_{k+1} = T_k * f_k |n.wo| / pdf_k.
 // A level whose BSDF sample fails returns 0 INCLUDING its own L_k (:105-106), so L_k is added only after the sample.
 template <bool COUNT>
-__global__ void __launch_bounds__(MCPT_BLOCK) render_recursive_kernel(DevScene sc, RenderParams p, float4* __restrict__ accum, DevCounters* gcnt) {
+__global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_recursive_kernel(DevScene sc, RenderParams p, float4* __restrict__ accum, DevCounters* gcnt) {
     __shared__ int s_stack[MCPT_STACK_DEPTH * MCPT_BLOCK];
     int* stk = s_stack + threadIdx.x;
     const uint32_t lb = xcd_band_block(blockIdx.x, gridDim.x);

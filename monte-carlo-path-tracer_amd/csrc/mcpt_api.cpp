@@ -3,8 +3,11 @@
 #include "../../include/mcpt.h"
 #include "kernels.h"
 #include "scene_build.h"
+#include "wavefront.h"
 
 #include <chrono>
+#include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,6 +37,20 @@ struct mcpt_ctx {
     uint64_t launches = 0;
     mcpt_scene_info info{};
     int width = 0, height = 0;
+    // ---- wavefront pipeline (the default for MCPT_INTEGRATOR_MIS)
+    bool use_wavefront = true;
+    PathPool pool{};
+    std::vector<DevBuf> pool_bufs;
+    DevBuf ctl_buf;
+    IterCtl* h_ctl = nullptr;          // pinned ring of control-block snapshots (termination check)
+    std::vector<hipEvent_t> chk_ev;
+    std::vector<hipEvent_t> k_ev;      // per-kernel event chain (only with detailed timing)
+    WaveTuning tune{};
+    uint32_t trace_grid = 0;
+    int n_cus = 0;
+    bool time_kernels = false;
+    double last_trace_ms = 0.0, total_trace_ms = 0.0, last_shade_ms = 0.0, total_shade_ms = 0.0;
+    uint64_t last_iterations = 0, total_iterations = 0;
 };
 
 namespace {
@@ -55,6 +72,11 @@ void destroy_ctx(mcpt_ctx* c) {
     (void)hipSetDevice(c->device);
     c->nodes.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_face.free_();
     c->mats.free_(); c->lights.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
+    for (auto& b : c->pool_bufs) b.free_();
+    c->ctl_buf.free_();
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    for (auto e : c->chk_ev) (void)hipEventDestroy(e);
+    for (auto e : c->k_ev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -65,6 +87,11 @@ mcpt_status use(mcpt_ctx* c) {
     if (!c) return fail(MCPT_ERR_INVALID_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     return MCPT_OK;
+}
+
+uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? uint32_t(std::strtoul(v, nullptr, 10)) : dflt;
 }
 
 // scratch device buffer for probes
@@ -125,8 +152,40 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     const size_t accum_bytes = size_t(c->width) * c->height * sizeof(float4);
     if ((e = c->accum_own.alloc(accum_bytes)) != hipSuccess) return bail(e, "alloc accumulator");
     if ((e = hipMemset(c->accum_own.p, 0, accum_bytes)) != hipSuccess) return bail(e, "clear accumulator");
-    if ((e = c->counters.alloc(sizeof(DevCounters))) != hipSuccess) return bail(e, "alloc counters");
-    if ((e = hipMemset(c->counters.p, 0, sizeof(DevCounters))) != hipSuccess) return bail(e, "clear counters");
+    if ((e = c->counters.alloc(sizeof(DevCounters) * WF_COUNTER_REPLICAS)) != hipSuccess) return bail(e, "alloc counters");
+    if ((e = hipMemset(c->counters.p, 0, sizeof(DevCounters) * WF_COUNTER_REPLICAS)) != hipSuccess) return bail(e, "clear counters");
+    {   // ---- wavefront pool.  Tunables are developer knobs (environment), not part of the ABI.
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, c->device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+        c->n_cus = prop.multiProcessorCount;
+        const char* pipe = std::getenv("MCPT_PIPELINE");
+        c->use_wavefront = !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS;
+        const uint64_t pixels = uint64_t(c->width) * c->height;
+        uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 22);
+        if (P < 2048) P = 2048;
+        c->pool.P = P;
+        c->tune.refill_at = env_u32("MCPT_WF_REFILL", 20); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 24);
+        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 40); c->tune.chunk = env_u32("MCPT_WF_CHUNK", 256);
+        c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0) != 0;
+        (void)pixels;
+        if (c->use_wavefront) {
+            c->pool_bufs.resize(10);
+            void** dst[10] = {(void**)&c->pool.ray_o, (void**)&c->pool.ray_d, (void**)&c->pool.hit, (void**)&c->pool.sh_d, (void**)&c->pool.nee,
+                              (void**)&c->pool.L, (void**)&c->pool.beta, (void**)&c->pool.sum, (void**)&c->pool.ids, (void**)&c->pool.shadow_queue};
+            for (int i = 0; i < 10; i++) {
+                const size_t bytes = i == 9 ? (size_t(P) + WF_SHARDS * MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * 16;
+                if ((e = c->pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
+                if ((e = hipMemset(c->pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
+                *dst[i] = c->pool_bufs[i].p;
+            }
+            if ((e = c->ctl_buf.alloc(sizeof(IterCtl))) != hipSuccess) return bail(e, "alloc IterCtl");
+            if ((e = hipHostMalloc((void**)&c->h_ctl, 8 * sizeof(IterCtl), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+            c->chk_ev.resize(8);
+            for (auto& ev : c->chk_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+            c->trace_grid = uint32_t(c->n_cus) * uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0));
+            c->trace_grid = env_u32("MCPT_WF_GRID", c->trace_grid);
+        }
+    }
     if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "sync after upload");
     c->accum = static_cast<float4*>(c->accum_own.p);
 
@@ -143,6 +202,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
     in.device_bytes = c->nodes.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_face.bytes + c->mats.bytes +
                       c->lights.bytes + c->texels.bytes + accum_bytes;
+    for (auto& b : c->pool_bufs) in.device_bytes += b.bytes;
     in.bvh_build_ms = hs.bvh_build_ms;
     in.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out_ctx = c;
@@ -169,7 +229,90 @@ static mcpt_status resolve_timing(mcpt_ctx* c) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->last_kernel_ms = ms; c->total_kernel_ms += ms; c->timing_pending = false;
+        if (c->use_wavefront) {
+            c->total_iterations += c->last_iterations;
+            if (c->time_kernels && c->last_iterations) {
+                double sh = 0.0, tr = 0.0;
+                for (uint64_t i = 0; i < c->last_iterations; i++) {
+                    float a_ = 0.f, b_ = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&a_, c->k_ev[2 * i], c->k_ev[2 * i + 1]));
+                    HIP_TRY(hipEventElapsedTime(&b_, c->k_ev[2 * i + 1], c->k_ev[2 * i + 2]));
+                    sh += a_; tr += b_;
+                }
+                c->last_shade_ms = sh; c->last_trace_ms = tr; c->total_shade_ms += sh; c->total_trace_ms += tr;
+            }
+        }
     }
+    return MCPT_OK;
+}
+
+static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p) {
+    // One mcpt_render call = a loop of [shade, trace] launches over the slot pool until every work item is finished.
+    const uint64_t tiles = uint64_t(p.tiles_x) * p.tiles_y;
+    const uint32_t n_items = uint32_t(tiles * 64 * p.chunks);
+    PathPool pool = ctx->pool;
+    const uint32_t want = uint32_t(((uint64_t(n_items) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
+    if (pool.P > want) pool.P = want;                                  // small jobs: do not sweep idle slots
+    pool.shard_cap = ((pool.P / MCPT_BLOCK + WF_SHARDS - 1) / WF_SHARDS) * MCPT_BLOCK;
+    IterCtl* ctl = static_cast<IterCtl*>(ctx->ctl_buf.p);
+    DevCounters* cnt = static_cast<DevCounters*>(ctx->counters.p);
+    HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(IterCtl), ctx->stream));
+    HIP_TRY(hipMemsetAsync(pool.beta, 0, size_t(pool.P) * 16, ctx->stream));    // every slot DEAD
+    HIP_TRY(hipMemsetAsync(pool.ids, 0, size_t(pool.P) * 16, ctx->stream));
+    HIP_TRY(hipMemsetAsync(pool.sum, 0, size_t(pool.P) * 16, ctx->stream));
+    const bool count = (p.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
+    const uint32_t CHECK = 4, RING = 8;
+    const bool debug = env_u32("MCPT_WF_DEBUG", 0) != 0;
+    const uint32_t max_it = env_u32("MCPT_WF_MAXIT", 1u << 20);
+    uint32_t it = 0, checks_issued = 0, checks_seen = 0;
+    size_t kev = 0;
+    bool done = false;
+    auto k_event = [&]() -> hipError_t {
+        if (!ctx->time_kernels) return hipSuccess;
+        if (kev == ctx->k_ev.size()) { hipEvent_t ev; hipError_t e = hipEventCreate(&ev); if (e != hipSuccess) return e; ctx->k_ev.push_back(ev); }
+        return hipEventRecord(ctx->k_ev[kev++], ctx->stream);
+    };
+    // consume finished control-block snapshots; `block` waits for the oldest one (ring full)
+    auto poll = [&](bool block) -> mcpt_status {
+        while (checks_seen < checks_issued) {
+            const uint32_t k = checks_seen % RING;
+            if (block) { HIP_TRY(hipEventSynchronize(ctx->chk_ev[k])); block = false; }
+            else {
+                hipError_t q = hipEventQuery(ctx->chk_ev[k]);
+                if (q == hipErrorNotReady) break;
+                if (q != hipSuccess) return hip_fail(q, "hipEventQuery");
+            }
+            const IterCtl& s = ctx->h_ctl[k];
+            const uint32_t it_of = (checks_seen + 1) * CHECK - 1;      // snapshot taken after iteration it_of
+            if (debug && checks_seen < 40)
+                fprintf(stderr, "[wf] it=%u active=%u shadow0=%u head=%u cursor0=%u/%u\n", it_of, s.any_active[it_of & 3], s.n_shadow[it_of & 3][0],
+                        s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(n_items, 0));
+            bool items_left = false;
+            for (uint32_t k = 0; k < WF_ITEM_SHARDS; k++) items_left |= s.item_cursor[k].v < wf_shard_capacity(n_items, k);
+            if (s.any_active[it_of & 3] == 0 && !items_left) done = true;
+            checks_seen++;
+        }
+        return MCPT_OK;
+    };
+    while (!done) {
+        HIP_TRY(k_event());
+        HIP_TRY(launch_wf_shade(ctx->dev, p, pool, ctl, it, n_items, ctx->accum, cnt, ctx->stream));
+        HIP_TRY(k_event());
+        HIP_TRY(launch_wf_trace(ctx->dev, pool, ctl, it, ctx->tune, count, cnt, ctx->trace_grid, ctx->stream));
+        it++;
+        if (it % CHECK == 0) {
+            mcpt_status ps = poll(checks_issued - checks_seen >= 2); if (ps != MCPT_OK) return ps;   // host runs at most 2 checks (8 iterations) ahead
+            if (done) break;
+            const uint32_t k = checks_issued % RING;
+            HIP_TRY(hipMemcpyAsync(&ctx->h_ctl[k], ctl, sizeof(IterCtl), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipEventRecord(ctx->chk_ev[k], ctx->stream));
+            checks_issued++;
+        }
+        mcpt_status ps = poll(false); if (ps != MCPT_OK) return ps;
+        if (it > max_it) return fail(MCPT_ERR_HIP, "wavefront loop did not terminate within MCPT_WF_MAXIT iterations");
+    }
+    HIP_TRY(k_event());
+    ctx->last_iterations = it;
     return MCPT_OK;
 }
 
@@ -184,10 +327,11 @@ mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t fir
     uint32_t spi = ctx->opts.samples_per_item;
     if (ctx->opts.flags & MCPT_FLAG_DETERMINISTIC) spi = spp;               // one lane owns a pixel for the whole call
     else if (spi == 0) {
-        // auto: long enough that the end-of-item tail (lanes idling while the slowest lane of the wave finishes) is small,
-        // short enough that there are >= ~16 waves per SIMD slot to balance across the chip (256 CUs x 16 waves)
+        // auto: long enough that per-item overheads (film atomics, tail of an item) vanish, short enough that there are
+        // many more items than lanes/slots so the work balances across the chip
         spi = 64;
-        while (spi > 8 && tiles * ((spp + spi - 1) / spi) < 256ull * 16 * 16) spi >>= 1;
+        const uint64_t want_items = ctx->use_wavefront ? 4ull * ctx->pool.P / 64 : 256ull * 16 * 16;
+        while (spi > 8 && tiles * ((spp + spi - 1) / spi) < want_items) spi >>= 1;
         if (spi > spp) spi = spp;
     }
     if (spi > spp) spi = spp;
@@ -195,9 +339,13 @@ mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t fir
     p.atomic_accum = p.chunks > 1 ? 1u : 0u;
     p.max_depth = ctx->opts.max_depth; p.flags = ctx->opts.flags; p.integrator = ctx->opts.integrator;
     p.seed_lo = uint32_t(seed); p.seed_hi = uint32_t(seed >> 32);
-    if (tiles * p.chunks > 0x3fffffffull) return fail(MCPT_ERR_UNSUPPORTED, "launch too large: lower spp per call or raise samples_per_item");
+    if (tiles * p.chunks > 0x3ffffffull) return fail(MCPT_ERR_UNSUPPORTED, "launch too large: lower spp per call or raise samples_per_item");
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(launch_render(ctx->dev, p, ctx->accum, static_cast<DevCounters*>(ctx->counters.p), ctx->stream));
+    if (ctx->use_wavefront) {
+        st = render_wavefront(ctx, p); if (st != MCPT_OK) return st;
+    } else {
+        HIP_TRY(launch_render(ctx->dev, p, ctx->accum, static_cast<DevCounters*>(ctx->counters.p), ctx->stream));
+    }
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timing_pending = true; ctx->launches++;
     return MCPT_OK;
@@ -246,21 +394,28 @@ mcpt_status mcpt_get_counters(mcpt_ctx* ctx, mcpt_counters* out) {
     if (!out) return fail(MCPT_ERR_INVALID_ARG, "null output");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     st = resolve_timing(ctx); if (st != MCPT_OK) return st;
-    DevCounters d;
-    HIP_TRY(hipMemcpy(&d, ctx->counters.p, sizeof d, hipMemcpyDeviceToHost));
+    std::vector<DevCounters> rep(WF_COUNTER_REPLICAS);               // kernels spread their atomics over replicas; sum them here
+    HIP_TRY(hipMemcpy(rep.data(), ctx->counters.p, sizeof(DevCounters) * WF_COUNTER_REPLICAS, hipMemcpyDeviceToHost));
+    DevCounters d; std::memset(&d, 0, sizeof d);
+    for (const DevCounters& r : rep) {
+        d.paths += r.paths; d.rays_primary += r.rays_primary; d.rays_continuation += r.rays_continuation; d.rays_shadow += r.rays_shadow;
+        d.box_tests += r.box_tests; d.tri_tests += r.tri_tests; d.shaded_hits += r.shaded_hits; d.texel_fetches += r.texel_fetches;
+        d.self_shadow_tests += r.self_shadow_tests; d.self_shadow_hits += r.self_shadow_hits;
+    }
     std::memset(out, 0, sizeof *out);
     out->paths = d.paths; out->rays_primary = d.rays_primary; out->rays_continuation = d.rays_continuation; out->rays_shadow = d.rays_shadow;
     out->box_tests = d.box_tests; out->tri_tests = d.tri_tests; out->shaded_hits = d.shaded_hits; out->texel_fetches = d.texel_fetches;
     out->self_shadow_tests = d.self_shadow_tests; out->self_shadow_hits = d.self_shadow_hits;
     out->kernel_ms = ctx->last_kernel_ms; out->kernel_ms_total = ctx->total_kernel_ms; out->launches = ctx->launches;
+    out->trace_ms_total = ctx->total_trace_ms; out->shade_ms_total = ctx->total_shade_ms; out->iterations = ctx->total_iterations;
     return MCPT_OK;
 }
 mcpt_status mcpt_reset_counters(mcpt_ctx* ctx) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemset(ctx->counters.p, 0, sizeof(DevCounters)));
+    HIP_TRY(hipMemset(ctx->counters.p, 0, sizeof(DevCounters) * WF_COUNTER_REPLICAS));
     st = resolve_timing(ctx); if (st != MCPT_OK) return st;
-    ctx->total_kernel_ms = 0.0; ctx->launches = 0;
+    ctx->total_kernel_ms = 0.0; ctx->launches = 0; ctx->total_trace_ms = 0.0; ctx->total_shade_ms = 0.0; ctx->total_iterations = 0;
     return MCPT_OK;
 }
 

@@ -1,0 +1,58 @@
+// Wavefront pipeline state: a pool of path SLOTS in HBM (structure of arrays, 16-B records, one slot per thread of the
+// shade kernel => fully coalesced), the shadow-ray queue, and the tiny control block the kernels use to hand over counts
+// without a host round trip.  See DESIGN.md §Kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "device_scene.h"
+
+#define SLOT_DEAD  0u   // no work item bound
+#define SLOT_ALIVE 1u   // a path is in flight; its extend ray was (or is about to be) traced
+#define SLOT_DRAIN 2u   // path ended in the same shade call that emitted its last shadow ray: finalise next call
+
+struct PathPool {
+    float4* ray_o;      // extend-ray origin xyz (= previous path vertex) | w: int bits = light triangle the pending shadow ray must skip
+    float4* ray_d;      // extend-ray direction xyz                        | w: 1.0f if an extend ray is pending this iteration, else 0
+    float4* hit;        // written by trace: int bits tri (leaf order, -1 = miss), u, v, t
+    float4* sh_d;       // pending shadow ray: direction xyz, t2 (origin = ray_o.xyz)
+    float4* nee;        // radiance the pending shadow ray carries if unoccluded (xyz)
+    float4* L;          // radiance of the current path so far xyz | w: pdf of the BSDF sample that produced the extend ray
+    float4* beta;       // path throughput xyz | w: uint bits  state(2) | prev_mirror(1) | bounce << 8
+    float4* sum;        // item accumulator: sum of finished samples xyz | w: number of finished samples
+    uint4* ids;         // pixel, current sample index, next sample index, end sample index
+    uint32_t* shadow_queue;   // slots with a pending shadow ray: WF_SHARDS regions of shard_cap entries, appended by shade, consumed by trace
+    uint32_t P;         // slots
+    uint32_t shard_cap; // capacity of one shadow-queue shard = ceil(blocks / WF_SHARDS) * MCPT_BLOCK
+};
+
+#define WF_SHARDS 8          // shadow-queue shards (block b appends to shard b % 8: 8x less contention on the cursor)
+#define WF_COUNTER_REPLICAS 1024
+#define WF_ITEM_SHARDS 64
+
+struct IterCtl {        // indexed [iteration & 3]; shade(it) zeroes entry (it+1)&3 for the next iteration
+    uint32_t trace_head[4];
+    uint32_t any_active[4];              // set (plain store) by any wave that still owns a live slot
+    uint32_t n_shadow[4][WF_SHARDS];     // entries appended to each shard of the shadow queue
+    uint32_t pad[8];
+    struct { uint32_t v; uint32_t pad[15]; } item_cursor[WF_ITEM_SHARDS];   // work-item cursors, one 64-B line each
+};
+
+// Work items are handed out in units of MCPT_BLOCK consecutive items; unit u belongs to shard u % WF_ITEM_SHARDS.
+// local index l of shard k  ->  global item ((l / MCPT_BLOCK) * WF_ITEM_SHARDS + k) * MCPT_BLOCK + l % MCPT_BLOCK
+__host__ __device__ inline uint32_t wf_shard_capacity(uint32_t n_items, uint32_t k) {
+    const uint32_t units = (n_items + MCPT_BLOCK - 1) / MCPT_BLOCK;
+    return units > k ? ((units - k + WF_ITEM_SHARDS - 1) / WF_ITEM_SHARDS) * MCPT_BLOCK : 0u;
+}
+
+struct WaveTuning {     // scheduler thresholds of the trace kernel (lanes out of 64)
+    uint32_t refill_at;       // refill when at least this many lanes are idle
+    uint32_t leaf_at;         // run the leaf block when at least this many lanes wait at a leaf
+    uint32_t inner_keep;      // keep iterating the inner-node block while at least this many lanes are at inner nodes
+    uint32_t chunk;           // rays a wave reserves per atomic on the queue head
+};
+
+hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
+                           float4* accum, DevCounters* cnt, hipStream_t stream);
+hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,
+                           DevCounters* cnt, uint32_t grid_blocks, hipStream_t stream);
+int wf_trace_blocks_per_cu(bool count);

@@ -1,0 +1,427 @@
+// Wavefront formulation of Render::render -> cast_Ray -> ray_tracing (Render.cpp:56-175) for gfx950.
+//
+// Why not one megakernel (kernels.hip keeps one for cross-checking): measured on MI355X the per-thread bounce loop keeps
+// the VALUs ~78 % busy at 14 % lane utilisation -- rays of one wave need very different numbers of BVH steps, only ~40 %
+// of the lanes own a shadow ray, and shading code inflates the traversal loop to 169 VGPRs (2 waves/SIMD).  Here the
+// path state lives in HBM (PathPool, 16-B records, one slot per lane => coalesced) and each iteration runs two kernels:
+//
+//   wf_shade_kernel  one lane per slot, every lane busy: consumes the hit of the slot's extend ray (emitter MIS, Russian
+//                    roulette, termination, film write, regeneration of the next camera ray) and produces the next
+//                    extend ray + at most one shadow ray (appended to a compact queue with one atomic per wave).
+//   wf_trace_kernel  persistent waves over the ray list [P extend slots | n_shadow queue entries]; closest-hit and any-hit
+//                    rays share one traversal loop.  Each wave schedules itself with __ballot/__popcll: it runs the
+//                    inner-node block while most lanes sit at inner nodes, the leaf block once enough lanes wait at a
+//                    leaf, and the refill block (write results back, pull fresh rays from a wave-private chunk of the
+//                    queue) once enough lanes are idle -- so the expensive blocks execute with well-packed lanes.
+//                    ~56 VGPRs -> LDS (32-entry per-lane stack) is the occupancy limit: 5 blocks = 20 waves / CU.
+#include "pt_device.h"
+#include "wavefront.h"
+
+__device__ __forceinline__ f3 xyz(const float4 v) { return mk3(v.x, v.y, v.z); }
+__device__ __forceinline__ float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ f3 wf_scrub_nan(f3 c) {        // Scene::set_Pixel (Scene.cpp:16-18)
+    if (c.x != c.x) c.x = 0.f;
+    if (c.y != c.y) c.y = 0.f;
+    if (c.z != c.z) c.z = 0.f;
+    return c;
+}
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {            // number of set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ uint32_t wave_first(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ====================================================================================================== shade
+template <bool COUNT>
+__global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, RenderParams p, PathPool pool, IterCtl* ctl, uint32_t it, uint32_t n_items,
+                                                              float4* __restrict__ accum, DevCounters* gcnt) {
+    const uint32_t slot = blockIdx.x * MCPT_BLOCK + threadIdx.x;           // pool.P is a multiple of MCPT_BLOCK
+    const uint32_t lane = threadIdx.x & 63;
+    if (slot < WF_SHARDS) { const uint32_t n = (it + 1) & 3; ctl->n_shadow[n][slot] = 0; if (slot == 0) { ctl->trace_head[n] = 0; ctl->any_active[n] = 0; } }
+    __shared__ uint32_t s_wave_cnt[MCPT_BLOCK / 64];
+    __shared__ uint32_t s_base, s_sel;
+
+    const float4 bt = pool.beta[slot];
+    const uint32_t st = __float_as_uint(bt.w);
+    uint32_t state = st & 3u;
+    bool prev_mirror = (st & 4u) != 0;
+    int bounce = (int)(st >> 8);
+    f3 beta = xyz(bt);
+    const float4 Lp = pool.L[slot];
+    f3 L = xyz(Lp);
+    float prev_pdf = Lp.w;
+    uint4 id = pool.ids[slot];                                              // pixel, sample, s_next, s_end
+    float4 sm = pool.sum[slot];
+    const float nl = (float)sc.n_lights;
+    const bool correct_t2 = (p.flags & MCPT_FLAG_CORRECT_SHADOW_T2) != 0;
+
+    bool terminated = false, emit_extend = false, emit_shadow = false, sum_dirty = false, id_dirty = false;
+    bool c_prim = false, c_cont = false, c_self_t = false, c_self_h = false, c_shaded = false;
+    uint32_t c_texel = 0;
+    f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1), sh_dir = mk3(0, 0, 1), nee = mk3(0, 0, 0);
+    float sh_t2 = 0.f; int sh_skip = -1;
+
+    if (state == SLOT_ALIVE) do {
+        const float4 h = pool.hit[slot];
+        const int tri = __float_as_int(h.x);
+        if (tri < 0) { terminated = true; break; }                                             // Render.cpp:118-119,144-145
+        const float hu = h.y, hv = h.z;
+        const f3 prev_p = xyz(pool.ray_o[slot]), d = xyz(pool.ray_d[slot]);
+        const HitShade hs = load_hit_shade(sc, tri, hu, hv, d);
+        const DevMaterial& mat = sc.mats[hs.mat];
+        const d3 p64 = hit_point64(sc, tri, hu, hv);
+        const f3 p32 = to_f3(p64);
+        c_shaded = true;
+        if (bounce > 0) {
+            if ((mat.flags & MAT_EMISSIVE) && hs.front) {                                       // Render.cpp:146-162
+                const f3 rad = mk3(mat.radiance[0], mat.radiance[1], mat.radiance[2]);
+                if (prev_mirror) L = L + beta * rad;
+                else {
+                    const f3 dd = prev_p - p32;
+                    const float len = length(dd);
+                    const float cosine = dot(normalize(dd), hs.n);
+                    float light_pdf = 0.f;
+                    if (cosine != 0.f) light_pdf = len * len / cosine / nl / tri_area(sc, tri);
+                    L = L + beta * rad * power_heuristic(prev_pdf, light_pdf);
+                }
+            }
+            if (bounce - 1 > 3) {                                                              // Render.cpp:164-170
+                const float q = fminf(max3(beta), 0.95f);
+                const Rng4 r = rng_block(id.x, id.y, 2u + 2u * (uint32_t)(bounce - 1), p.seed_lo, p.seed_hi);
+                if (r.v[2] > q) { terminated = true; break; }
+                beta = beta / q;
+            }
+        }
+        if (p.max_depth != 0 && (uint32_t)bounce >= p.max_depth) { terminated = true; break; }  // `bounces < max_depth`
+        if (bounce == 0 && (mat.flags & MAT_EMIT_0)) L = L + mk3(mat.radiance[0], mat.radiance[1], mat.radiance[2]);   // :121-122
+
+        const f3 kd = tex_color(sc, mat, hs.tu, hs.tv, c_texel);
+        const Bsdf bsdf = make_bsdf(mat, kd, hs.n, -d);
+        const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
+        const Rng4 rb = rng_block(id.x, id.y, 2u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
+        const LightSample ls = sample_light(sc, p64, ra.v[0], ra.v[1], ra.v[2], true);         // Render.cpp:124
+        if (ls.pdf != 0.f) {
+            c_self_t = true; c_self_h = ls.self_hit;
+            if (correct_t2 || !ls.self_hit) {
+                f3 fx; float bpdf;
+                bsdf_eval(bsdf, ls.wo, fx, bpdf);
+                const float cos_theta = fabsf(dot(hs.n, ls.wo));
+                const float weight = power_heuristic(ls.pdf / nl, bpdf);
+                nee = weight * beta * ls.rad * fx * cos_theta / ls.pdf * nl;                    // Render.cpp:127-129
+                sh_dir = ls.wo; sh_t2 = ls.t2; sh_skip = ls.tri; emit_shadow = true;
+            }
+        }
+        no = p32;                                                                               // both new rays start at the hit point
+        const Scatter s = bsdf_sample(bsdf, ra.v[3], rb.v[0], rb.v[1]);                         // Render.cpp:133-134
+        if (s.pdf == 0.f) {                                                                     // Render.cpp:135-136: path ends, but its last
+            state = SLOT_DRAIN;                                                                 // shadow ray is still in flight -> finalise next call
+            break;
+        }
+        const float cos_theta = fabsf(dot(hs.n, s.wo));
+        beta = beta * (s.f * cos_theta / s.pdf);                                                // Render.cpp:140
+        prev_pdf = s.pdf; prev_mirror = s.mirror;
+        nd = s.wo; bounce++;
+        emit_extend = true; c_cont = true;
+    } while (0);
+    else if (state == SLOT_DRAIN) terminated = true;
+
+    if (terminated) {                                                                           // Scene::set_Pixel, per sample
+        const f3 c = wf_scrub_nan(L);
+        sm.x += c.x; sm.y += c.y; sm.z += c.z; sm.w += 1.f; sum_dirty = true;
+        state = SLOT_DEAD;
+    }
+    bool want_item = false;
+    if (state == SLOT_DEAD && id.z == id.w) {                                                   // item exhausted (or never had one)
+        if (sm.w > 0.f) {                                                                       // film: sum + count (Scene.cpp:19-20)
+            float* a = reinterpret_cast<float*>(accum + id.x);
+            if (p.atomic_accum) { atomicAdd(a + 0, sm.x); atomicAdd(a + 1, sm.y); atomicAdd(a + 2, sm.z); atomicAdd(a + 3, sm.w); }
+            else { float4 cur = accum[id.x]; cur.x += sm.x; cur.y += sm.y; cur.z += sm.z; cur.w += sm.w; accum[id.x] = cur; }
+            sm = make_float4(0.f, 0.f, 0.f, 0.f); sum_dirty = true;
+        }
+        want_item = true;
+    }
+    // ---- pull new work items: one atomic per BLOCK on one of WF_ITEM_SHARDS cursors (own shard first, then a few others);
+    //      a plain load screens out exhausted shards so the end-of-render tail costs no atomics at all
+    {
+        const uint32_t wv_ = threadIdx.x >> 6;
+        const uint64_t m = __ballot(want_item);
+        if (lane == 0) s_wave_cnt[wv_] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+            uint32_t base = 0xffffffffu, sel = 0;
+            if (tot) {
+                for (uint32_t probe = 0; probe < 4; probe++) {
+                    const uint32_t k = (blockIdx.x + probe * 17u) & (WF_ITEM_SHARDS - 1);
+                    const uint32_t cap = wf_shard_capacity(n_items, k);
+                    if (__hip_atomic_load(&ctl->item_cursor[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cap) {
+                        const uint32_t b = atomicAdd(&ctl->item_cursor[k].v, tot);
+                        if (b < cap) { base = b; sel = k; break; }
+                    }
+                }
+            }
+            s_base = base; s_sel = sel;
+        }
+        __syncthreads();
+        if (want_item) {
+            id.z = id.w = 0; id_dirty = true;
+            if (s_base != 0xffffffffu) {
+                uint32_t before = 0;
+                for (uint32_t k = 0; k < wv_; k++) before += s_wave_cnt[k];
+                const uint32_t l = s_base + before + lane_rank(m);
+                const uint32_t item = ((l / MCPT_BLOCK) * WF_ITEM_SHARDS + s_sel) * MCPT_BLOCK + (l % MCPT_BLOCK);
+                if (item < n_items) {
+                    const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+                    const uint32_t wv = item >> 6, il = item & 63u;
+                    const uint32_t chunk = wv / n_tiles, tile = wv - chunk * n_tiles;
+                    const uint32_t px = (tile % p.tiles_x) * 8 + (il & 7), py = (tile / p.tiles_x) * 8 + (il >> 3);
+                    if (px < (uint32_t)sc.cam.width && py < (uint32_t)sc.cam.height) {
+                        id.x = py * (uint32_t)sc.cam.width + px;
+                        id.z = p.first_sample + chunk * p.samples_per_item;
+                        id.w = p.first_sample + min(p.spp, (chunk + 1) * p.samples_per_item);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                                        // s_wave_cnt / s_base are reused below
+    }
+    if (state == SLOT_DEAD && id.z < id.w) {                                                    // next sample of the item: camera ray
+        id.y = id.z++; id_dirty = true;
+        const Rng4 r = rng_block(id.x, id.y, 0u, p.seed_lo, p.seed_hi);
+        const int px = (int)(id.x % (uint32_t)sc.cam.width), py = (int)(id.x / (uint32_t)sc.cam.width);
+        cast_ray(sc.cam, px, py, r.v[0], r.v[1], no, nd);                                       // Render.cpp:64
+        beta = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f); bounce = 0; prev_pdf = 0.f; prev_mirror = false;
+        state = SLOT_ALIVE; emit_extend = true; c_prim = true;
+    }
+
+    // ---- write the slot back
+    pool.beta[slot] = mk4(beta, __uint_as_float(state | (prev_mirror ? 4u : 0u) | ((uint32_t)bounce << 8)));
+    pool.L[slot] = mk4(L, prev_pdf);
+    if (emit_extend || emit_shadow) pool.ray_o[slot] = mk4(no, __int_as_float(sh_skip));
+    pool.ray_d[slot] = mk4(nd, emit_extend ? 1.f : 0.f);
+    if (emit_shadow) { pool.sh_d[slot] = mk4(sh_dir, sh_t2); pool.nee[slot] = mk4(nee, 0.f); }
+    if (sum_dirty) pool.sum[slot] = sm;
+    if (id_dirty) pool.ids[slot] = id;
+
+    // ---- shadow queue append: ranks inside the block through LDS, ONE atomic per block on the block's shard cursor
+    const uint32_t cur = it & 3, wv = threadIdx.x >> 6, shard = blockIdx.x & (WF_SHARDS - 1);
+    const uint64_t ms = __ballot(emit_shadow);
+    if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(ms);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        s_base = tot ? atomicAdd(&ctl->n_shadow[cur][shard], tot) : 0u;
+    }
+    __syncthreads();
+    if (emit_shadow) {
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
+        pool.shadow_queue[shard * pool.shard_cap + s_base + before + lane_rank(ms)] = slot;
+    }
+    // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
+    const uint64_t ma = __ballot(state != SLOT_DEAD);
+    const uint64_t m_term = __ballot(terminated), m_prim = __ballot(c_prim), m_cont = __ballot(c_cont);
+    const uint64_t m_st = __ballot(c_self_t), m_sh = __ballot(c_self_h), m_shaded = __ballot(c_shaded);
+    unsigned long long texels = 0;
+    if (COUNT) { texels = c_texel; for (int off = 32; off > 0; off >>= 1) texels += __shfl_xor(texels, off, 64); }
+    if (lane == 0) {
+        DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1));
+        if (ma) ctl->any_active[cur] = 1u;
+        if (m_term) atomicAdd(&g->paths, (unsigned long long)__popcll(m_term));
+        if (m_prim) atomicAdd(&g->rays_primary, (unsigned long long)__popcll(m_prim));
+        if (m_cont) atomicAdd(&g->rays_continuation, (unsigned long long)__popcll(m_cont));
+        if (ms) atomicAdd(&g->rays_shadow, (unsigned long long)__popcll(ms));
+        if (m_st) atomicAdd(&g->self_shadow_tests, (unsigned long long)__popcll(m_st));
+        if (m_sh) atomicAdd(&g->self_shadow_hits, (unsigned long long)__popcll(m_sh));
+        if (COUNT) { if (m_shaded) atomicAdd(&g->shaded_hits, (unsigned long long)__popcll(m_shaded)); if (texels) atomicAdd(&g->texel_fetches, texels); }
+    }
+}
+
+// ====================================================================================================== trace
+// BVH_node::hit / has_hit (BVH.cpp:95-136), AABB::Intersection (AABB.cpp:25-36), Triangle::hit / isIntersect
+// (Triangle.cpp:48-106) for the whole ray list of one iteration.  Acceptance rules: see bvh_traverse in pt_device.h.
+template <bool COUNT>
+__global__ void __launch_bounds__(MCPT_BLOCK) wf_trace_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt) {
+    __shared__ int s_stack[MCPT_STACK_DEPTH * MCPT_BLOCK];
+    int* stk = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t P = pool.P;
+    uint32_t sh_end[WF_SHARDS];            // exclusive prefix ends of the shadow shards in the ray list (uniform -> SGPRs)
+    {
+        uint32_t acc = P;
+        for (int q = 0; q < WF_SHARDS; q++) { acc += ctl->n_shadow[it & 3][q]; sh_end[q] = acc; }
+    }
+    const uint32_t total = sh_end[WF_SHARDS - 1];
+    uint32_t* head = &ctl->trace_head[it & 3];
+
+    // wave-private slice of the ray list: the first chunk is assigned statically (no atomic), later ones come from `head`
+    const uint32_t n_waves = gridDim.x * (MCPT_BLOCK / 64);
+    uint32_t w_next = (blockIdx.x * (MCPT_BLOCK / 64) + (threadIdx.x >> 6)) * tune.chunk;
+    uint32_t w_end = min(w_next + tune.chunk, total);
+    bool exhausted = false;
+    if (w_next >= total) { w_next = w_end = 0; }
+
+    bool have = false, any = false, blocked = false;
+    uint32_t slot = 0; int skip = -1;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+    float idx = 0, idy = 0, idz = 0, oodx = 0, oody = 0, oodz = 0, tmax = 0;
+    int node = MCPT_NODE_SENTINEL, sp = 1;
+    int htri = -1; float ht = 0, hu = 0, hv = 0;
+    uint32_t n_box = 0, n_tri = 0;
+
+    for (;;) {
+        const bool at_inner = have && node >= 0;
+        const bool at_leaf = have && node < 0 && node != MCPT_NODE_SENTINEL;
+        const int n_inner = __popcll(__ballot(at_inner)), n_leaf = __popcll(__ballot(at_leaf));
+        const int n_idle = 64 - n_inner - n_leaf;
+
+        if ((n_inner + n_leaf == 0) || (!exhausted && n_idle >= (int)tune.refill_at)) {
+            // ------------------------------------------------------------------ refill block
+            if (have && node == MCPT_NODE_SENTINEL) {                    // finished: write the result back
+                if (any) {
+                    if (!blocked) {                                      // Render.cpp:125-130: unoccluded -> L += NEE term
+                        const float4 n4 = pool.nee[slot]; float4 l4 = pool.L[slot];
+                        l4.x += n4.x; l4.y += n4.y; l4.z += n4.z;
+                        pool.L[slot] = l4;
+                    }
+                } else {
+                    pool.hit[slot] = make_float4(__int_as_float(htri), hu, hv, ht);
+                }
+                have = false;
+            }
+            if (!exhausted) {
+                const uint64_t m_idle = __ballot(!have);
+                if (w_next == w_end) {                                   // reserve the next chunk of the list (uniform branch)
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head, tune.chunk);
+                    base = wave_first(base) + n_waves * tune.chunk;
+                    if (base >= total) exhausted = true;
+                    else { w_next = base; w_end = min(base + tune.chunk, total); }
+                }
+                if (!exhausted) {
+                    const uint32_t w = w_next + lane_rank(m_idle);
+                    if (!have && w < w_end) {
+                        bool valid;
+                        if (w < P) {                                     // extend ray of slot w
+                            slot = w;
+                            const float4 rd = pool.ray_d[w];
+                            valid = rd.w != 0.f;
+                            const float4 ro = pool.ray_o[w];
+                            o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; skip = -1;
+                        } else {                                         // shadow ray of a queued slot
+                            uint32_t q = 0, lo = P;
+                            for (int k = 0; k < WF_SHARDS - 1; k++) if (w >= sh_end[k]) { q = k + 1; lo = sh_end[k]; }
+                            slot = pool.shadow_queue[q * pool.shard_cap + (w - lo)];
+                            const float4 ro = pool.ray_o[slot], sd = pool.sh_d[slot];
+                            o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; skip = __float_as_int(ro.w); valid = true;
+                        }
+                        if (valid) {
+                            const float tiny = 1e-30f;
+                            idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+                            idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+                            idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+                            oodx = o.x * idx; oody = o.y * idy; oodz = o.z * idz;
+                            stk[0] = MCPT_NODE_SENTINEL; sp = 1; node = 0;
+                            htri = -1; ht = 0.f; hu = 0.f; hv = 0.f; blocked = false;
+                            have = true;
+                        }
+                    }
+                    w_next = min(w_next + (uint32_t)__popcll(m_idle), w_end);
+                }
+            }
+            if (exhausted && __ballot(have) == 0) break;
+            continue;
+        }
+
+        if (n_leaf >= (int)tune.leaf_at || n_inner == 0) {
+            // ------------------------------------------------------------------ leaf block (all lanes waiting at a leaf)
+            if (at_leaf) {
+                const uint32_t leaf = (uint32_t)~node;
+                const uint32_t first = leaf >> 3, cnt = leaf & 7u;
+                bool done = false;
+                for (uint32_t i = 0; i < cnt && !done; i++) {
+                    const int ti = (int)(first + i);
+                    if (ti == skip) continue;
+                    const float4* T = sc.tri_isect + 3 * (size_t)ti;
+                    const float4 v0 = T[0], e1 = T[1], e2 = T[2];
+                    if (COUNT) n_tri++;
+                    const float hx = d.y * e2.z - e2.y * d.z, hy = d.z * e2.x - e2.z * d.x, hz = d.x * e2.y - e2.x * d.y;
+                    const float a = e1.x * hx + e1.y * hy + e1.z * hz;
+                    const float sx = o.x - v0.x, sy = o.y - v0.y, sz = o.z - v0.z;
+                    const float qx = sy * e1.z - e1.y * sz, qy = sz * e1.x - e1.z * sx, qz = sx * e1.y - e1.x * sy;
+                    const float inv_a = __builtin_amdgcn_rcpf(a);
+                    const float u = (sx * hx + sy * hy + sz * hz) * inv_a;
+                    const float v = (d.x * qx + d.y * qy + d.z * qz) * inv_a;
+                    const float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv_a;
+                    if (any) {                                           // Triangle::isIntersect
+                        if (fabsf(a) >= 1e-6f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && t >= 1e-4f && t <= tmax) { blocked = true; done = true; }
+                    } else {                                             // Triangle::hit
+                        if (fabsf(a) >= 0.00001f && t >= 1e-4f && t < tmax && u >= 0.0f && v >= 0.0f && (1.0f - u - v) >= 0.0f) { tmax = t; htri = ti; ht = t; hu = u; hv = v; }
+                    }
+                }
+                if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
+                else { sp--; node = stk[sp * MCPT_BLOCK]; }
+            }
+            continue;
+        }
+
+        // ---------------------------------------------------------------------- inner-node block
+        do {
+            if (have && node >= 0) {
+                const float4* n = sc.nodes + 4 * (size_t)node;
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                const float c0x0 = fmaf(n0.x, idx, -oodx), c0x1 = fmaf(n0.y, idx, -oodx);
+                const float c0y0 = fmaf(n0.z, idy, -oody), c0y1 = fmaf(n0.w, idy, -oody);
+                const float c0z0 = fmaf(n2.x, idz, -oodz), c0z1 = fmaf(n2.y, idz, -oodz);
+                const float c1x0 = fmaf(n1.x, idx, -oodx), c1x1 = fmaf(n1.y, idx, -oodx);
+                const float c1y0 = fmaf(n1.z, idy, -oody), c1y1 = fmaf(n1.w, idy, -oody);
+                const float c1z0 = fmaf(n2.z, idz, -oodz), c1z1 = fmaf(n2.w, idz, -oodz);
+                const float c0n = fmaxf(fmaxf(fminf(c0x0, c0x1), fminf(c0y0, c0y1)), fmaxf(fminf(c0z0, c0z1), 1e-4f));
+                const float c0f = fminf(fminf(fmaxf(c0x0, c0x1), fmaxf(c0y0, c0y1)), fminf(fmaxf(c0z0, c0z1), tmax));
+                const float c1n = fmaxf(fmaxf(fminf(c1x0, c1x1), fminf(c1y0, c1y1)), fmaxf(fminf(c1z0, c1z1), 1e-4f));
+                const float c1f = fminf(fminf(fmaxf(c1x0, c1x1), fmaxf(c1y0, c1y1)), fminf(fmaxf(c1z0, c1z1), tmax));
+                const bool h0 = c0n <= c0f, h1 = c1n <= c1f;
+                if (COUNT) n_box += 2;
+                const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
+                if (h0 && h1) {
+                    const bool swp = c1n < c0n;
+                    node = swp ? ch1 : ch0;
+                    stk[sp * MCPT_BLOCK] = swp ? ch0 : ch1;
+#ifdef MCPT_EXPERIMENT_CLAMP_STACK
+                    if (sp < MCPT_STACK_DEPTH - 1)     // timing experiment only: drops entries on overflow (wrong image, safe memory)
+#endif
+                    sp++;
+                } else if (h0) node = ch0;
+                else if (h1) node = ch1;
+                else { sp--; node = stk[sp * MCPT_BLOCK]; }
+            }
+        } while (__popcll(__ballot(have && node >= 0)) >= (int)tune.inner_keep);
+    }
+
+    if (COUNT) {
+        unsigned long long b = n_box, t = n_tri;
+        for (int off = 32; off > 0; off >>= 1) { b += __shfl_xor(b, off, 64); t += __shfl_xor(t, off, 64); }
+        if (lane == 0) { DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1)); atomicAdd(&g->box_tests, b); atomicAdd(&g->tri_tests, t); }
+    }
+}
+
+// ====================================================================================================== launchers
+hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
+                           float4* accum, DevCounters* cnt, hipStream_t stream) {
+    const dim3 grid(pool.P / MCPT_BLOCK), block(MCPT_BLOCK);
+    if (p.flags & MCPT_FLAG_COUNT_TRAVERSAL) hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, stream, sc, p, pool, ctl, iteration, n_items, accum, cnt);
+    else hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, stream, sc, p, pool, ctl, iteration, n_items, accum, cnt);
+    return hipGetLastError();
+}
+hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,
+                           DevCounters* cnt, uint32_t grid_blocks, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(grid_blocks), dim3(MCPT_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt);
+    else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(grid_blocks), dim3(MCPT_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt);
+    return hipGetLastError();
+}
+int wf_trace_blocks_per_cu(bool count) {
+    int n = 0;
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, MCPT_BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<false>, MCPT_BLOCK, 0);
+    if (e != hipSuccess || n <= 0) n = 4;
+    return n;
+}
