@@ -4,7 +4,8 @@
 Metric (BASELINE.json): Mray/s (primary + continuation + shadow rays actually traversed) on S-cornell, the synthetic
 stand-in for cornell-box (the cg24 scene files are not in the reference repo), 800x800, 1024 spp, depth 8 = configs[1].
 
-One "step" = one full 800x800x1024-spp render of the scene already resident in HBM (one mcpt_render call).  With N > 1
+One "step" = one full 800x800x1024-spp render of the scene already resident in HBM (one mcpt_render call = a stream of
+[shade, trace] kernel launches over the HBM path pool).  With N > 1
 ranks (one process per GPU, launched by torch.distributed.run) every rank renders the full 1024 spp of ITS OWN sample
 range (rank r, step s -> samples [(s*N + r)*1024, ...)), then the fp32 accumulators are summed with one RCCL all-reduce
 inside the timed region -- the path's only exchange step.  Work per GPU is fixed => "scaling": "weak".
@@ -28,7 +29,10 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, SPP, DEPTH = 800, 800, 1024, 8
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per unit of work with THIS build's layouts
-B_BOX, B_TRI, B_SHADED, B_TEXEL, B_LIGHT = 32, 48, 64 + 72, 16, 72 + 64
+B_BOX, B_TRI = 32, 48            # half a 64-B two-child node per slab test; one 48-B {v0,e1,e2} record per triangle test
+B_RAY = 32 + 16                  # trace kernel: ray fetch (origin + direction records) + 16-B result write-back per ray
+B_SHADED, B_TEXEL, B_LIGHT = 64 + 72, 16, 72 + 64     # shade kernel: shading record + fp64 corners; texel; light corners + light record
+B_SLOT = 7 * 16 + 4 * 16         # shade kernel: slot state read (7 records) + written back (4 records) per visited slot
 
 
 def cpu_baseline(pkg, scene, rays_per_path_ref, budget_s=20.0):
@@ -61,6 +65,10 @@ def cpu_baseline(pkg, scene, rays_per_path_ref, budget_s=20.0):
                 "sample": "200x200x4spp S-cornell depth %d through oracle/mcpt_oracle.cpp (OpenMP, %d threads, %.2f s)" % (DEPTH, ncores, t)}
 
 
+def ri_info_nodes(r):
+    return r.info().n_nodes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +93,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    os.environ["MCPT_TIME_KERNELS"] = "1"       # HIP-event pair around every kernel launch, on the launch stream
+    mg = __import__("importlib").import_module("mcpt_amd.multigpu")
     scene = pkg.scenes.cornell_box(WIDTH, HEIGHT)
     r = pkg.Renderer(scene, max_depth=DEPTH, device=local)
     accum = torch.zeros(HEIGHT * WIDTH * 4, dtype=torch.float32, device=dev)      # torch lends memory + stream + RCCL
@@ -93,9 +103,8 @@ def main():
     r.set_stream(stream.cuda_stream)
 
     def step(s):
-        r.render(args.spp, seed=20251004, first_sample=(s * world + rank) * args.spp)
-        if world > 1:
-            dist.all_reduce(accum)          # RCCL sum over xGMI on the same stream
+        r.render(args.spp, seed=20251004, first_sample=mg.first_sample(s, rank, world, args.spp))
+        mg.all_reduce_film(accum)           # RCCL sum over xGMI on the same stream (no-op for one rank)
 
     def fence():
         if world > 1:
@@ -123,24 +132,33 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- kernel duration: the library brackets every launch of the timed region with a HIP event pair recorded on
-        # the launch stream (torch's current stream, bound above); kernel_ms_total sums them since reset_counters()
-        k_ms = c.kernel_ms_total / max(1, c.launches)
-        rays_per_launch = c.rays / max(1, args.steps)
+        # ---- kernel durations: the library brackets every launch of the timed region with HIP events recorded on the launch
+        # stream (torch's current stream, bound above); *_ms_total sum them since reset_counters().  Dominant kernel =
+        # wf_trace_kernel (BVH traversal); one launch of it per pipeline iteration.
+        launches = max(1, c.iterations)
+        trace_ms = c.trace_ms_total / launches
+        shade_ms = c.shade_ms_total / launches
+        rays_per_launch = c.rays / launches
         # ---- algorithmic bytes per ray from an instrumented pass (same scene / depth / seed, 32 spp)
         ri = pkg.Renderer(scene, max_depth=DEPTH, device=local, flags=pkg.FLAG_COUNT_TRAVERSAL)
         ri.render(32, seed=20251004); ci = ri.counters(); ri.close()
-        bytes_per_ray = (B_BOX * ci.box_tests + B_TRI * ci.tri_tests + B_SHADED * ci.shaded_hits + B_TEXEL * ci.texel_fetches +
-                         B_LIGHT * ci.self_shadow_tests) / max(1, ci.rays)
-        film_bytes = 2 * 16 * WIDTH * HEIGHT
-        algo_bytes = bytes_per_ray * rays_per_launch + film_bytes
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        trace_bytes_per_ray = (B_BOX * ci.box_tests + B_TRI * ci.tri_tests) / max(1, ci.rays) + B_RAY
+        algo_bytes = trace_bytes_per_ray * rays_per_launch
+        achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):            # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_passes.sh), same workload
+            traffic = json.load(open(tpath)).get("wf_trace_kernel_hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": "render_mis_kernel<false,false>", "kernel_ms": round(k_ms, 3),
-                    "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": "wf_trace_kernel<false>", "kernel_ms": round(trace_ms, 4), "launches_per_step": round(launches / max(1, args.steps), 1),
+                    "algorithmic_bytes_per_ray": round(trace_bytes_per_ray, 1),
                     "box_tests_per_ray": round(ci.box_tests / max(1, ci.rays), 2), "tri_tests_per_ray": round(ci.tri_tests / max(1, ci.rays), 2),
-                    "note": "algorithmic bytes are served mostly by L1/L2 for this %.1f MB scene; see DESIGN.md" % (r.info().device_bytes / 1e6)}
+                    "second_kernel": {"kernel": "wf_shade_kernel<false>", "kernel_ms": round(shade_ms, 4),
+                                      "share_of_step": round(c.shade_ms_total / max(1e-9, c.kernel_ms_total), 3)},
+                    "note": "algorithmic bytes of BVH traversal are mostly served by L1/L2 (scene = %.1f MB of nodes+triangles); the HBM "
+                            "traffic of this kernel is the ray/hit stream of the path pool -- see DESIGN.md" % (
+                                (ri_info_nodes(r) * 64 + r.info().n_tris * 48) / 1e6)}
         rpp_ref = (c.rays_primary + c.rays_continuation + c.self_shadow_tests) / max(1, c.paths)
         out = {
             "metric": "Mray/s (primary+secondary), cornell-box 1024spp", "value": round(total_rays / dt / 1e6, 2), "unit": "Mray/s",

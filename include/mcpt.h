@@ -126,6 +126,9 @@ typedef struct mcpt_ctx mcpt_ctx;
  * uploads everything to HBM.  Allocates a zeroed width*height accumulator. */
 mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcpt_ctx** out_ctx);
 mcpt_status mcpt_destroy(mcpt_ctx* ctx);
+/* Host-only half of mcpt_create: validates `scene` (same error codes) and runs the same flatten + BVH build, without
+ * touching a device.  Fills n_tris / n_lights / n_nodes / bvh_depth / max_leaf / width / height / bvh_build_ms. */
+mcpt_status mcpt_check_scene(const mcpt_scene_desc* scene, mcpt_scene_info* out_info);
 mcpt_status mcpt_get_scene_info(const mcpt_ctx* ctx, mcpt_scene_info* out);
 const char* mcpt_last_error(void);   /* thread-local, valid until the next failing call on this thread */
 uint32_t    mcpt_abi_version(void);

@@ -137,6 +137,10 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:          # torch bundles its own libamdhip64: let it load first so both sides share one HIP runtime in this process
+        import torch  # noqa: F401
+    except Exception:
+        pass
     path = os.environ.get("MCPT_LIB_PATH", LIB_PATH)     # developer override: A/B another build of the same ABI
     if not os.path.exists(path):
         raise RuntimeError("libmcpt_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -147,6 +151,7 @@ def load_library() -> C.CDLL:
     sigs = {
         "mcpt_create": [P(SceneDesc), P(Opts), P(vp)],
         "mcpt_destroy": [vp],
+        "mcpt_check_scene": [P(SceneDesc), P(SceneInfo)],
         "mcpt_get_scene_info": [vp, P(SceneInfo)],
         "mcpt_render": [vp, C.c_uint32, C.c_uint64, C.c_uint32],
         "mcpt_sync": [vp],
@@ -177,7 +182,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "mcpt_create", "mcpt_destroy", "mcpt_get_scene_info", "mcpt_last_error", "mcpt_abi_version",
+    "mcpt_create", "mcpt_destroy", "mcpt_check_scene", "mcpt_get_scene_info", "mcpt_last_error", "mcpt_abi_version",
     "mcpt_render", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap",
     "mcpt_get_counters", "mcpt_reset_counters", "mcpt_bind_accum", "mcpt_accum_device_ptr", "mcpt_set_stream",
     "mcpt_probe_trace", "mcpt_probe_cast_ray", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
@@ -191,6 +196,15 @@ class McptError(RuntimeError):
 
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def check_scene(scene: "scenes.SceneData"):
+    """Host-only validation + BVH build (no device needed).  Returns (status, SceneInfo, message)."""
+    lib = load_library()
+    holder = DescHolder(scene)
+    info = SceneInfo()
+    st = lib.mcpt_check_scene(C.byref(holder.desc), C.byref(info))
+    return st, info, (lib.mcpt_last_error() or b"").decode() if st != MCPT_OK else ""
 
 
 class Renderer:

@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_mis_kernel(
     bool alive = false;
     uint32_t sample = 0; int bounce = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), beta = mk3(1, 1, 1), L = mk3(0, 0, 0), prev_p = mk3(0, 0, 0);
+    d3 o64 = mkd(0, 0, 0);                     // fp64 origin of the ray in flight (reference: Ray::start is a dvec3)
     float prev_pdf = 0.f; bool prev_mirror = false;
 
     for (;;) {
@@ -88,11 +89,11 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_mis_kernel(
             if (s_next == s_end) break;
             sample = s_next++;
             if (PROBE) {
-                o = mk3((float)probe_o[3 * pixel], (float)probe_o[3 * pixel + 1], (float)probe_o[3 * pixel + 2]);
+                o64 = mkd(probe_o[3 * pixel], probe_o[3 * pixel + 1], probe_o[3 * pixel + 2]); o = to_f3(o64);
                 d = mk3((float)probe_d[3 * pixel], (float)probe_d[3 * pixel + 1], (float)probe_d[3 * pixel + 2]);
             } else {
                 const Rng4 r = rng_block(pixel, sample, 0u, p.seed_lo, p.seed_hi);
-                cast_ray(sc.cam, px, py, r.v[0], r.v[1], o, d);                               // Render.cpp:64
+                cast_ray(sc.cam, px, py, r.v[0], r.v[1], o64, o, d);                          // Render.cpp:64
             }
             beta = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f); bounce = 0; alive = true;
             lc.paths++; lc.prim++;
@@ -104,10 +105,10 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_mis_kernel(
         const bool hit = bvh_traverse<false, COUNT>(sc, o, d, 1e-4f, 3.0e38f, -1, stk, tri, ht, hu, hv, lc.tc);
         if (!hit) { sum = sum + scrub_nan(L); alive = false; continue; }                      // Render.cpp:118-119,144-145
 
+        const d3 p64 = hit_point64(sc, tri, o64, d, hu, hv);
+        const f3 p32 = to_f3(p64);
         const HitShade hs = load_hit_shade(sc, tri, hu, hv, d);
         const DevMaterial& mat = sc.mats[hs.mat];
-        const d3 p64 = hit_point64(sc, tri, hu, hv);
-        const f3 p32 = to_f3(p64);
         if (COUNT) lc.shaded++;
 
         if (bounce > 0) {
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_mis_kernel(
         const float cos_theta = fabsf(dot(hs.n, sc_.wo));
         beta = beta * (sc_.f * cos_theta / sc_.pdf);                                          // Render.cpp:140
         prev_p = p32; prev_pdf = sc_.pdf; prev_mirror = sc_.mirror;
-        o = p32; d = sc_.wo;
+        o = p32; o64 = p64; d = sc_.wo;
         bounce++;
     }
 
@@ -219,19 +220,22 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_recursive_k
     f3 sum = mk3(0.f, 0.f, 0.f);
     bool alive = false; uint32_t sample = 0; int depth = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), T = mk3(1, 1, 1), L = mk3(0, 0, 0);
+    d3 o64 = mkd(0, 0, 0);
 
     for (;;) {
         if (!alive) {
             if (s_next == s_end) break;
             sample = s_next++;
             const Rng4 r = rng_block(pixel, sample, 0u, p.seed_lo, p.seed_hi);
-            cast_ray(sc.cam, px, py, r.v[0], r.v[1], o, d);
+            cast_ray(sc.cam, px, py, r.v[0], r.v[1], o64, o, d);
             T = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f); depth = 0; alive = true;
             lc.paths++; lc.prim++;
         } else lc.cont++;
         int tri = -1; float ht = 0.f, hu = 0.f, hv = 0.f;
         const bool hit = bvh_traverse<false, COUNT>(sc, o, d, 1e-4f, 3.0e38f, -1, stk, tri, ht, hu, hv, lc.tc);
         if (!hit) { sum = sum + scrub_nan(L); alive = false; continue; }                      // :90-93
+        const d3 p64 = hit_point64(sc, tri, o64, d, hu, hv);
+        const f3 p32 = to_f3(p64);
         const HitShade hs = load_hit_shade(sc, tri, hu, hv, d);
         const DevMaterial& mat = sc.mats[hs.mat];
         if (COUNT) lc.shaded++;
@@ -239,8 +243,6 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_recursive_k
             L = L + T * mk3(mat.radiance[0], mat.radiance[1], mat.radiance[2]);
             sum = sum + scrub_nan(L); alive = false; continue;
         }
-        const d3 p64 = hit_point64(sc, tri, hu, hv);
-        const f3 p32 = to_f3(p64);
         const f3 kd = tex_color(sc, mat, hs.tu, hs.tv, lc.texel);
         const Rng4 ra = rng_block(pixel, sample, 1u + 2u * (uint32_t)depth, p.seed_lo, p.seed_hi);
         const Rng4 rb = rng_block(pixel, sample, 2u + 2u * (uint32_t)depth, p.seed_lo, p.seed_hi);
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_recursive_k
         if (length(s.wo) < 0.00001f) { sum = sum + scrub_nan(L); alive = false; continue; }    // :105-106 (drops L_k too)
         L = L + T * Lk;
         T = T * (s.f * fabsf(dot(hs.n, s.wo))) / s.pdf;                                       // :108
-        o = p32; d = s.wo; depth++;
+        o = p32; o64 = p64; d = s.wo; depth++;
         if (depth > maxd) { sum = sum + scrub_nan(L); alive = false; continue; }              // :85-87
     }
     if (valid && n_samples) {
@@ -310,8 +312,8 @@ __global__ void __launch_bounds__(MCPT_BLOCK) probe_trace_kernel(DevScene sc, ui
 __global__ void probe_cast_ray_kernel(DevScene sc, uint32_t n, const int* xy, const float* xi, float* out6) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    f3 o, d;
-    cast_ray(sc.cam, xy[2 * i], xy[2 * i + 1], xi[2 * i], xi[2 * i + 1], o, d);
+    f3 o, d; d3 o64;
+    cast_ray(sc.cam, xy[2 * i], xy[2 * i + 1], xi[2 * i], xi[2 * i + 1], o64, o, d);
     out6[6 * i + 0] = o.x; out6[6 * i + 1] = o.y; out6[6 * i + 2] = o.z; out6[6 * i + 3] = d.x; out6[6 * i + 4] = d.y; out6[6 * i + 5] = d.z;
 }
 

@@ -117,6 +117,20 @@ extern "C" {
 uint32_t mcpt_abi_version(void) { return MCPT_ABI_VERSION; }
 const char* mcpt_last_error(void) { return g_err.c_str(); }
 
+mcpt_status mcpt_check_scene(const mcpt_scene_desc* scene, mcpt_scene_info* out_info) {
+    if (!scene) return fail(MCPT_ERR_INVALID_ARG, "mcpt_check_scene: null argument");
+    HostScene hs; std::string err;
+    mcpt_status st = build_host_scene(scene, hs, err);
+    if (st != MCPT_OK) return fail(st, err);
+    if (out_info) {
+        std::memset(out_info, 0, sizeof *out_info);
+        out_info->n_tris = uint32_t(hs.tri_face.size()); out_info->n_lights = uint32_t(hs.lights.size()); out_info->n_nodes = uint32_t(hs.nodes.size() / 4);
+        out_info->bvh_depth = hs.bvh_depth; out_info->max_leaf = hs.max_leaf; out_info->width = uint32_t(scene->camera.width); out_info->height = uint32_t(scene->camera.height);
+        out_info->bvh_build_ms = hs.bvh_build_ms;
+    }
+    return MCPT_OK;
+}
+
 mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcpt_ctx** out_ctx) {
     if (!scene || !out_ctx) return fail(MCPT_ERR_INVALID_ARG, "mcpt_create: null argument");
     *out_ctx = nullptr;
@@ -124,14 +138,14 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if (opts) std::memcpy(&o, opts, std::min<size_t>(sizeof o, opts->struct_size ? opts->struct_size : sizeof o));
     if (o.integrator > MCPT_INTEGRATOR_RECURSIVE_NEE) return fail(MCPT_ERR_INVALID_ARG, "unknown integrator");
 
+    HostScene hs; std::string err;
+    mcpt_status st = build_host_scene(scene, hs, err);
+    if (st != MCPT_OK) return fail(st, err);
+
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(MCPT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (o.device < 0 || o.device >= ndev) return fail(MCPT_ERR_NO_DEVICE, "device ordinal out of range");
-
-    HostScene hs; std::string err;
-    mcpt_status st = build_host_scene(scene, hs, err);
-    if (st != MCPT_OK) return fail(st, err);
 
     mcpt_ctx* c = new mcpt_ctx();
     c->device = o.device; c->opts = o; c->width = scene->camera.width; c->height = scene->camera.height;
@@ -169,11 +183,12 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0) != 0;
         (void)pixels;
         if (c->use_wavefront) {
-            c->pool_bufs.resize(10);
-            void** dst[10] = {(void**)&c->pool.ray_o, (void**)&c->pool.ray_d, (void**)&c->pool.hit, (void**)&c->pool.sh_d, (void**)&c->pool.nee,
-                              (void**)&c->pool.L, (void**)&c->pool.beta, (void**)&c->pool.sum, (void**)&c->pool.ids, (void**)&c->pool.shadow_queue};
-            for (int i = 0; i < 10; i++) {
-                const size_t bytes = i == 9 ? (size_t(P) + WF_SHARDS * MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * 16;
+            c->pool_bufs.resize(11);
+            void** dst[11] = {(void**)&c->pool.ray_o, (void**)&c->pool.ray_d, (void**)&c->pool.hit, (void**)&c->pool.sh_d, (void**)&c->pool.nee,
+                              (void**)&c->pool.L, (void**)&c->pool.beta, (void**)&c->pool.sum, (void**)&c->pool.ids, (void**)&c->pool.shadow_queue,
+                              (void**)&c->pool.org64};
+            for (int i = 0; i < 11; i++) {
+                const size_t bytes = i == 9 ? (size_t(P) + WF_SHARDS * MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * (i == 10 ? 32 : 16);
                 if ((e = c->pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
                 if ((e = hipMemset(c->pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
                 *dst[i] = c->pool_bufs[i].p;

@@ -58,7 +58,7 @@ DEV Rng4 rng_block(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t see
 // ---------------------------------------------------------------------------------------------- camera
 // Render::cast_Ray (Render.cpp:71-80): (x + xi)/w in float, the rest in double; tan/normalize/cross hoisted to
 // DevCamera by the host.  `up` is used raw (SURVEY A-17).
-DEV void cast_ray(const DevCamera& c, int x, int y, float xi_x, float xi_y, f3& o, f3& d) {
+DEV void cast_ray(const DevCamera& c, int x, int y, float xi_x, float xi_y, d3& o64, f3& o, f3& d) {
     double u = ((double)(((float)x + xi_x) / (float)c.width) - 0.5) * c.h * (double)c.width / (double)c.height;
     double v = ((double)(((float)y + xi_y) / (float)c.height) - 0.5) * c.h;
     double dx = c.front[0] + u * c.right[0] + v * c.up[0];
@@ -66,7 +66,8 @@ DEV void cast_ray(const DevCamera& c, int x, int y, float xi_x, float xi_y, f3& 
     double dz = c.front[2] + u * c.right[2] + v * c.up[2];
     double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
     d = mk3((float)(dx * inv), (float)(dy * inv), (float)(dz * inv));
-    o = mk3((float)c.eye[0], (float)c.eye[1], (float)c.eye[2]);
+    o64 = mkd(c.eye[0], c.eye[1], c.eye[2]);
+    o = to_f3(o64);
 }
 
 // ---------------------------------------------------------------------------------------------- traversal
@@ -167,11 +168,23 @@ DEV HitShade load_hit_shade(const DevScene& sc, int tri, float u, float v, f3 d)
     h.front = dot(h.n, d) < 0.0f;
     return h;
 }
-// the fp64 hit point (Triangle.cpp:35-38 with the fp32 barycentrics promoted)
-DEV d3 hit_point64(const DevScene& sc, int tri, float u, float v) {
+// The hit record's fp64 part, exactly as Triangle::hit computes it (Triangle.cpp:48-68): the fp32 traversal only SELECTS the
+// triangle; u, v and the hit point are then recomputed by one fp64 Moller-Trumbore from the fp64 ray origin (the previous
+// hit point, or the eye) and the fp32-valued direction.  This keeps the low-order bits of the hit point statistically
+// identical to the reference's -- they decide the light self-occlusion of SURVEY A-9 (with fp32 barycentrics the point is
+// exactly fp32-representable on axis-aligned walls and the image comes out 1.2 % darker than the reference).
+DEV d3 hit_point64(const DevScene& sc, int tri, d3 o64, f3 dir, float& u_out, float& v_out) {
     const double* P = sc.tri_pos64 + 9 * (size_t)tri;
-    const double b1 = (double)u, b2 = (double)v;
-    return (1.0 - b1 - b2) * ld_d3(P) + b1 * ld_d3(P + 3) + b2 * ld_d3(P + 6);
+    const d3 v0 = ld_d3(P), v1 = ld_d3(P + 3), v2 = ld_d3(P + 6);
+    const d3 e1 = v1 - v0, e2 = v2 - v0, dd = to_d3(dir);
+    const d3 h = cross(dd, e2);
+    const double inv_a = 1.0 / dot(e1, h);
+    const d3 s = o64 - v0;
+    const double u = dot(s, h) * inv_a;
+    const d3 q = cross(s, e1);
+    const double v = dot(dd, q) * inv_a;
+    u_out = (float)u; v_out = (float)v;
+    return (1.0 - u - v) * v0 + u * v1 + v * v2;
 }
 // Triangle::area (Triangle.cpp:24-28) from the fp32 edges already stored for intersection
 DEV float tri_area(const DevScene& sc, int tri) {
@@ -325,14 +338,20 @@ DEV LightSample sample_light(const DevScene& sc, d3 p64, float xi_l, float xi_u,
     const float w = 1.f - u - v;
     const f3 normal = normalize(mk3(w * lt.n0[0] + u * lt.n1[0] + v * lt.n2[0], w * lt.n0[1] + u * lt.n1[1] + v * lt.n2[1],
                                     w * lt.n0[2] + u * lt.n1[2] + v * lt.n2[2]));
-    const f3 d = point - to_f3(p64);
-    const f3 dir = normalize(d);
-    const float d2 = dot(d, d);
+    // The next five values feed the fp64 self-hit predicate below, whose verdict hangs on their LAST BIT (SURVEY A-9): they are
+    // computed with the reference's exact rounding sequence (glm: products and sums rounded one by one, (x*x + y*y) + z*z,
+    // v * (1 / sqrt(dot)); Render.cpp:208-213,217) -- the _rn intrinsics keep hipcc from fusing them into FMAs, which would
+    // shift the self-occlusion rate (measured: image 1.2 % darker than the reference with contraction on).
+    const f3 po = to_f3(p64);
+    const f3 d = mk3(__fsub_rn(point.x, po.x), __fsub_rn(point.y, po.y), __fsub_rn(point.z, po.z));
+    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(d.x, d.x), __fmul_rn(d.y, d.y)), __fmul_rn(d.z, d.z));
+    const float inv_len = __fdiv_rn(1.0f, __fsqrt_rn(d2));
+    const f3 dir = mk3(__fmul_rn(d.x, inv_len), __fmul_rn(d.y, inv_len), __fmul_rn(d.z, inv_len));
     const float cs = dot(-dir, normal);
     LightSample ls;
     ls.pdf = 0.f;
     if (!guard || cs != 0.f) ls.pdf = d2 / cs / lt.area;
-    ls.wo = dir; ls.rad = mk3(lt.radiance[0], lt.radiance[1], lt.radiance[2]); ls.t2 = length(d); ls.tri = lt.tri;
+    ls.wo = dir; ls.rad = mk3(lt.radiance[0], lt.radiance[1], lt.radiance[2]); ls.t2 = __fsqrt_rn(d2); ls.tri = lt.tri;
     // fp64 Moller-Trumbore any-hit on the sampled triangle only
     const d3 e1 = v1 - v0, e2 = v2 - v0, dd = to_d3(dir);
     const d3 h = cross(dd, e2);

@@ -20,6 +20,7 @@ struct PathPool {
     float4* beta;       // path throughput xyz | w: uint bits  state(2) | prev_mirror(1) | bounce << 8
     float4* sum;        // item accumulator: sum of finished samples xyz | w: number of finished samples
     uint4* ids;         // pixel, current sample index, next sample index, end sample index
+    double4* org64;     // fp64 origin of the extend ray (reference: Ray::start is a dvec3); read only by shade
     uint32_t* shadow_queue;   // slots with a pending shadow ray: WF_SHARDS regions of shard_cap entries, appended by shade, consumed by trace
     uint32_t P;         // slots
     uint32_t shard_cap; // capacity of one shadow-queue shard = ceil(blocks / WF_SHARDS) * MCPT_BLOCK

@@ -58,18 +58,20 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
     bool c_prim = false, c_cont = false, c_self_t = false, c_self_h = false, c_shaded = false;
     uint32_t c_texel = 0;
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1), sh_dir = mk3(0, 0, 1), nee = mk3(0, 0, 0);
+    d3 no64 = mkd(0, 0, 0);
     float sh_t2 = 0.f; int sh_skip = -1;
 
     if (state == SLOT_ALIVE) do {
         const float4 h = pool.hit[slot];
         const int tri = __float_as_int(h.x);
         if (tri < 0) { terminated = true; break; }                                             // Render.cpp:118-119,144-145
-        const float hu = h.y, hv = h.z;
+        float hu, hv;
         const f3 prev_p = xyz(pool.ray_o[slot]), d = xyz(pool.ray_d[slot]);
+        const double4 og = pool.org64[slot];                                                    // fp64 origin of the traced ray
+        const d3 p64 = hit_point64(sc, tri, mkd(og.x, og.y, og.z), d, hu, hv);
+        const f3 p32 = to_f3(p64);
         const HitShade hs = load_hit_shade(sc, tri, hu, hv, d);
         const DevMaterial& mat = sc.mats[hs.mat];
-        const d3 p64 = hit_point64(sc, tri, hu, hv);
-        const f3 p32 = to_f3(p64);
         c_shaded = true;
         if (bounce > 0) {
             if ((mat.flags & MAT_EMISSIVE) && hs.front) {                                       // Render.cpp:146-162
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
                 sh_dir = ls.wo; sh_t2 = ls.t2; sh_skip = ls.tri; emit_shadow = true;
             }
         }
-        no = p32;                                                                               // both new rays start at the hit point
+        no = p32; no64 = p64;                                                                   // both new rays start at the hit point
         const Scatter s = bsdf_sample(bsdf, ra.v[3], rb.v[0], rb.v[1]);                         // Render.cpp:133-134
         if (s.pdf == 0.f) {                                                                     // Render.cpp:135-136: path ends, but its last
             state = SLOT_DRAIN;                                                                 // shadow ray is still in flight -> finalise next call
@@ -188,7 +190,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
         id.y = id.z++; id_dirty = true;
         const Rng4 r = rng_block(id.x, id.y, 0u, p.seed_lo, p.seed_hi);
         const int px = (int)(id.x % (uint32_t)sc.cam.width), py = (int)(id.x / (uint32_t)sc.cam.width);
-        cast_ray(sc.cam, px, py, r.v[0], r.v[1], no, nd);                                       // Render.cpp:64
+        cast_ray(sc.cam, px, py, r.v[0], r.v[1], no64, no, nd);                                 // Render.cpp:64
         beta = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f); bounce = 0; prev_pdf = 0.f; prev_mirror = false;
         state = SLOT_ALIVE; emit_extend = true; c_prim = true;
     }
@@ -198,6 +200,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
     pool.L[slot] = mk4(L, prev_pdf);
     if (emit_extend || emit_shadow) pool.ray_o[slot] = mk4(no, __int_as_float(sh_skip));
     pool.ray_d[slot] = mk4(nd, emit_extend ? 1.f : 0.f);
+    if (emit_extend) pool.org64[slot] = make_double4(no64.x, no64.y, no64.z, 0.0);
     if (emit_shadow) { pool.sh_d[slot] = mk4(sh_dir, sh_t2); pool.nee[slot] = mk4(nee, 0.f); }
     if (sum_dirty) pool.sum[slot] = sm;
     if (id_dirty) pool.ids[slot] = id;

@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REAL reference (oracle/_ref, built by oracle/build_ref.sh from /root/reference).
+
+The reference has no tests, fixtures or golden vectors of its own, and its scene files are absent, so
+every pin is produced here: inputs are drawn with fixed numpy seeds, pushed through the reference's own functions via
+oracle/ref/ref_driver.cpp (random numbers injected through oracle/ref/ref_shim.h where a function draws any), and the
+inputs + outputs are stored.  Only DATA is stored -- no reference source.  Run where /root/reference exists:
+
+    python tests/golden/make_golden.py
+
+Files:
+  ref_kats.npz         function-level known-answer vectors (AABB, triangle, BSDF, texture, camera, light sampling, film)
+  ref_paths.npz        path-level vectors: (pixel, xi sequence) -> radiance of Render::ray_tracing, both integrators,
+                       plus BVH::hit / has_hit on random rays, on the S-cornell-small scene
+  ref_images.npz       per-pixel mean / variance images of the reference renderer (64x64) for statistical parity
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle as orc  # noqa: E402
+
+pkg = orc.pkg
+
+
+def rand_xi(rng, n):
+    return (rng.randint(0, 1 << 24, n).astype(np.float32) / np.float32(1 << 24)).astype(np.float32)
+
+
+def unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def kats(ref):
+    rng = np.random.RandomState(20251004)
+    out = {}
+    # ---- AABB::Intersection
+    n = 3000
+    A = rng.uniform(-1, 1, (n, 3)); B = A + rng.uniform(0, 1, (n, 3)) * (rng.rand(n, 3) > 0.1)   # some flat boxes
+    o = rng.uniform(-2, 2, (n, 3))
+    aim = A + (B - A) * rng.uniform(-0.15, 1.15, (n, 3))                                           # mostly towards the box, some near misses
+    d = np.where(rng.rand(n, 1) < 0.75, unit(aim - o), unit(rng.normal(size=(n, 3))))
+    d[::17, 0] = 0.0; d[::23, 1] = 0.0                                                            # axis-parallel rays (inf / nan slabs)
+    o[::34] = np.where(rng.rand(len(o[::34]), 3) < 0.5, A[::34], o[::34])                          # origins on a slab plane: 0 * inf = nan
+    d = unit(d)
+    t1 = np.full(n, 1e-4); t2 = np.where(rng.rand(n) < 0.5, np.finfo(np.float64).max, rng.uniform(0.1, 3, n))
+    res = np.array([ref.aabb_intersect(A[i], B[i], o[i], d[i], t1[i], t2[i]) for i in range(n)], np.int32)
+    out.update(aabb_A=A, aabb_B=B, aabb_o=o, aabb_d=d, aabb_t1=t1, aabb_t2=t2, aabb_hit=res)
+    # ---- Triangle::hit / isIntersect / area
+    n = 3000
+    v = rng.uniform(-1, 1, (n, 9)); v[::11, 3:6] = v[::11, 0:3] + 1e-4 * rng.normal(size=(len(v[::11]), 3))   # slivers -> |a| threshold
+    vn = unit(rng.normal(size=(n, 3, 3))).reshape(n, 9); uv = rng.uniform(0, 1, (n, 6))
+    tgt = (v.reshape(n, 3, 3) * rng.dirichlet((1, 1, 1), n)[:, :, None]).sum(1) + 0.05 * rng.normal(size=(n, 3)) * (rng.rand(n, 1) < 0.3)
+    o = rng.uniform(-2, 2, (n, 3)); d = unit(tgt - o)
+    t2 = np.where(rng.rand(n) < 0.6, np.finfo(np.float64).max, rng.uniform(0.1, 4, n))
+    em = (rng.rand(n) < 0.3).astype(np.int32)
+    hit = np.zeros(n, np.int32); rec = np.zeros((n, 13)); anyh = np.zeros(n, np.int32); area = np.zeros(n, np.float32)
+    for i in range(n):
+        hit[i], rec[i] = ref.tri_hit(v[i], vn[i], uv[i], em[i], o[i], d[i], 1e-4, t2[i])
+        anyh[i] = ref.tri_any(v[i], o[i], d[i], 1e-4, t2[i])
+        area[i] = ref.tri_area(v[i])
+    out.update(tri_v=v, tri_vn=vn, tri_uv=uv, tri_em=em, tri_o=o, tri_d=d, tri_t2=t2, tri_hit=hit, tri_rec=rec, tri_any=anyh, tri_area=area)
+    # ---- BSDF: setup / eval / sample over the three lobe configurations
+    n = 1500
+    nrm = unit(rng.normal(size=(n, 3))); wi = unit(rng.normal(size=(n, 3))); wo = unit(rng.normal(size=(n, 3))).astype(np.float32)
+    kd = rng.uniform(0, 1, (n, 3)); ks = rng.uniform(0, 1, (n, 3)); ns = rng.choice([1.0, 10.0, 50.0, 1000.0, 5000.0, 10000.0, 20000.0], n)
+    kind = rng.randint(0, 4, n)
+    ks[kind == 0] = 0.0                        # diffuse only
+    kd[kind == 3] = 0.0; ks[kind == 3] = 0.0   # black: uninitialised weights in the reference (A-12) -> recorded but not compared
+    nrm[::13] = np.array([0.95, 0.1, 0.1]) / np.linalg.norm([0.95, 0.1, 0.1])    # |n.x| > 0.9 branch of the ONB
+    xi = np.stack([rand_xi(rng, n), rand_xi(rng, n), rand_xi(rng, n)], 1)
+    setup = np.zeros((n, 18), np.float32); ev = np.zeros((n, 4), np.float32); smp = np.zeros((n, 8), np.float32); used = np.zeros(n, np.int32)
+    for i in range(n):
+        setup[i] = ref.bsdf_setup(nrm[i], wi[i], kd[i], ks[i], ns[i])
+        ev[i] = ref.bsdf_eval(nrm[i], wi[i], kd[i], ks[i], ns[i], wo[i])
+        smp[i], used[i] = ref.bsdf_sample(nrm[i], wi[i], kd[i], ks[i], ns[i], xi[i])
+    out.update(bsdf_n=nrm, bsdf_wi=wi, bsdf_wo=wo, bsdf_kd=kd, bsdf_ks=ks, bsdf_ns=ns, bsdf_kind=kind, bsdf_xi=xi, bsdf_setup=setup,
+               bsdf_eval=ev, bsdf_sample=smp, bsdf_used=used)
+    # ---- utils
+    a = rng.uniform(0, 5, 500).astype(np.float32); b = rng.uniform(0, 5, 500).astype(np.float32); a[::50] = 0; b[::50] = 0
+    out.update(ph_a=a, ph_b=b, ph=np.array([ref.power_heuristic(float(x), float(y)) for x, y in zip(a, b)], np.float32))
+    c = np.concatenate([rng.uniform(-0.5, 1.5, 200), [0.999, 0.9991, 1.0, 0.0, -0.0]]).astype(np.float32)
+    out.update(clamp_in=c, clamp_out=np.array([ref.L.ref_clamp01(float(x)) for x in c]))
+    # ---- Texture::get_color on an 8x5 image
+    img = rng.uniform(0, 1, (5, 8, 3)).astype(np.float32)
+    uvs = np.concatenate([rng.uniform(-2, 3, (300, 2)), [[0.0, 0.0], [1.0, 1.0], [0.9995, 0.9995], [-0.0001, 2.0]]])
+    out.update(tex_img=img, tex_uv=uvs, tex_rgb=np.array([ref.texture_get_color(img, u, v) for u, v in uvs], np.float32))
+    # ---- film: set_Pixel NaN scrub + getPixelsColor tonemap on the loaded scene's film (whatever its size)
+    return out
+
+
+def scene_vectors(ref, scene, tag):
+    rng = np.random.RandomState(777)
+    out = {}
+    w, h = scene.camera.width, scene.camera.height
+    # Render::cast_Ray
+    n = 400
+    xy = np.stack([rng.randint(0, w, n), rng.randint(0, h, n)], 1).astype(np.int32); xi = np.stack([rand_xi(rng, n), rand_xi(rng, n)], 1)
+    od = np.zeros((n, 6))
+    for i in range(n):
+        od[i], _ = ref.cast_ray(int(xy[i, 0]), int(xy[i, 1]), xi[i])
+    out.update({tag + "cam_xy": xy, tag + "cam_xi": xi, tag + "cam_od": od})
+    # BVH::hit / has_hit on random rays from inside the box
+    n = 4000
+    o = rng.uniform(0.05, 0.95, (n, 3)); d = unit(rng.normal(size=(n, 3)))
+    rec = np.zeros((n, 12)); hit = np.zeros(n, np.int32); anyh = np.zeros(n, np.int32); t2 = rng.uniform(0.05, 1.5, n)
+    for i in range(n):
+        hit[i], rec[i] = ref.bvh_hit(o[i], d[i])
+        anyh[i] = ref.bvh_has_hit(o[i], d[i], 1e-4, t2[i])
+    out.update({tag + "ray_o": o, tag + "ray_d": d, tag + "ray_hit": hit, tag + "ray_rec": rec, tag + "ray_t2": t2, tag + "ray_any": anyh})
+    # Render::sample from points inside the box
+    n = 600
+    p = rng.uniform(0.05, 0.9, (n, 3)); xi = np.stack([rand_xi(rng, n) for _ in range(3)], 1)
+    ls = np.zeros((n, 14))
+    for i in range(n):
+        ls[i], _ = ref.sample_light(p[i], xi[i])
+    out.update({tag + "ls_p": p, tag + "ls_xi": xi, tag + "ls_out": ls})
+    # full paths through Render::ray_tracing(Ray&): pixel + injected xi sequence -> radiance
+    n, m = 3000, 192
+    xy = np.stack([rng.randint(0, w, n), rng.randint(0, h, n)], 1).astype(np.int32)
+    xi = np.stack([rand_xi(rng, m) for _ in range(n)], 0)
+    L = np.zeros((n, 3), np.float32); used = np.zeros(n, np.int32)
+    for i in range(n):
+        L[i], used[i] = ref.trace_pixel(int(xy[i, 0]), int(xy[i, 1]), xi[i])
+    assert ref.underflow() == 0 and used.max() < m, "xi budget too small"
+    keep = used.max() + 2
+    out.update({tag + "path_xy": xy, tag + "path_xi": xi[:, :keep].copy(), tag + "path_L": L, tag + "path_used": used})
+    # the dead recursive integrator Render::ray_tracing(Ray&,int)
+    n = 800
+    o = rng.uniform(0.1, 0.9, (n, 3)); d = unit(rng.normal(size=(n, 3))); xi = np.stack([rand_xi(rng, m) for _ in range(n)], 0)
+    L = np.zeros((n, 3), np.float32); used = np.zeros(n, np.int32)
+    for i in range(n):
+        L[i], used[i] = ref.trace_path(o[i], d[i], xi[i], recursive=True)
+    assert used.max() < m
+    out.update({tag + "rec_o": o, tag + "rec_d": d, tag + "rec_xi": xi[:, :used.max() + 2].copy(), tag + "rec_L": L, tag + "rec_used": used})
+    # light self-occlusion (SURVEY A-9): fraction of light samples whose shadow ray the sampled triangle itself blocks
+    n = 4000
+    o = rng.uniform(0.1, 0.9, (n, 3)); d = unit(rng.normal(size=(n, 3))); xi = np.stack([rand_xi(rng, n) for _ in range(3)], 1)
+    ok = np.zeros(n, np.int32); res = np.zeros((n, 2), np.int32)
+    for i in range(n):
+        ok[i], res[i] = ref.shadow_probe(o[i], d[i], xi[i], 1e-4)
+    out.update({tag + "sp_o": o, tag + "sp_d": d, tag + "sp_xi": xi, tag + "sp_ok": ok, tag + "sp_res": res})
+    return out
+
+
+def film_vectors(ref):
+    rng = np.random.RandomState(5)
+    ref.clear()
+    w, h = ref.width, ref.height
+    vals = rng.uniform(0, 2, (h, w, 3)).astype(np.float32)
+    vals[0, 0] = [np.nan, 0.5, 0.25]; vals[1, 1] = [0.3, np.nan, np.nan]; vals[2, 2] = [np.inf, 0.1, 0.2]
+    for rep in range(3):
+        for y in range(h):
+            for x in range(w):
+                ref.set_pixel(x, y, vals[y, x] * (rep + 1))
+    return {"film_vals": vals, "film_accum": ref.accum(), "film_u8": ref.pixels_u8()}
+
+
+def image_stats(scene, lib_depth, max_bounces, frames, batches):
+    """Mean and variance-of-the-mean images from `batches` independent batches of `frames` spp of the real reference."""
+    ref = orc.Reference(depth_variant=lib_depth)
+    tmp = tempfile.mkdtemp(prefix="mcpt_golden_")
+    ref.load(scene.write(tmp))
+    ref.stream_mode()
+    if max_bounces:
+        ref.set_max_bounces(max_bounces)
+    means = []
+    for b in range(batches):
+        ref.clear(); ref.render(frames)
+        a = ref.accum(); means.append(a[..., :3] / a[..., 3:])
+    means = np.stack(means)
+    return means.mean(0).astype(np.float32), (means.var(0, ddof=1) / batches).astype(np.float32)
+
+
+def main():
+    os.environ["OMP_NUM_THREADS"] = "1"     # the reference's global mt19937 is racy across threads; single-threaded = reproducible
+    scene = pkg.scenes.cornell_box_small(64, 64)
+    tmp = tempfile.mkdtemp(prefix="mcpt_golden_")
+    ref = orc.Reference()
+    ref.load(scene.write(tmp))
+    k = kats(ref)
+    k.update(film_vectors(ref))
+    np.savez_compressed(os.path.join(HERE, "ref_kats.npz"), **k)
+    p = scene_vectors(ref, scene, "cs_")
+    st = ref.bvh_stats()
+    p.update(cs_bvh=np.array([st["nodes"], st["leaves"], st["depth"], st["max_leaf"], ref.num_tris(), ref.num_lights()], np.int64))
+    np.savez_compressed(os.path.join(HERE, "ref_paths.npz"), **p)
+    print("kats + paths written")
+    # images need fresh Reference objects per scene (the driver holds one scene); ctypes loads the same .so once, so run
+    # each in a subprocess-free way: Reference() reloads via ref_load.
+    imgs = {}
+    m, v = image_stats(scene, False, 0, 64, 16); imgs.update(cs_unbounded_mean=m, cs_unbounded_var=v)
+    m, v = image_stats(scene, True, 4, 64, 16); imgs.update(cs_depth4_mean=m, cs_depth4_var=v)
+    ob = pkg.scenes.open_box(48, 48)
+    m, v = image_stats(ob, False, 0, 64, 16); imgs.update(ob_unbounded_mean=m, ob_unbounded_var=v)
+    np.savez_compressed(os.path.join(HERE, "ref_images.npz"), **imgs)
+    print("images written")
+
+
+if __name__ == "__main__":
+    main()

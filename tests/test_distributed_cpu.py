@@ -1,0 +1,36 @@
+"""CPU test of the N > 1 path (gloo, world_size 2): sample-range sharding + one film all-reduce per step reproduces the
+single-process render of the union of the sample ranges.  The renderer here is the CPU oracle (no GPU in this container);
+bench.py runs the same two helpers (multigpu.first_sample / all_reduce_film) around the HIP renderer with backend nccl."""
+import os
+import socket
+
+import numpy as np
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_ranks_equal_one_process(pkg, orc, tmp_path):
+    import torch.multiprocessing as mp
+    from tests import dist_worker
+    world, spp, steps = 2, 3, 2
+    out = str(tmp_path / "film.npy")
+    mp.spawn(dist_worker.run, args=(world, _free_port(), spp, steps, out), nprocs=world, join=True)
+    film = np.load(out)
+    o = orc.Oracle(pkg.scenes.open_box(16, 16), max_depth=4)
+    want, _, _ = o.render(world * spp * steps, seed=11, first_sample=0, threads=1)
+    assert np.array_equal(film[..., 3], want[..., 3])                 # every pixel got world*spp*steps samples, counts reduce too
+    assert np.allclose(film[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)   # same samples, different fp32 summation order
+
+
+def test_sample_ranges_are_disjoint_and_contiguous(pkg):
+    from importlib import import_module
+    mg = import_module("mcpt_amd.multigpu")
+    for world in (1, 2, 4, 8):
+        seen = []
+        for step in range(3):
+            for r in range(world):
+                f = mg.first_sample(step, r, world, 1024)
+                seen.extend(range(f, f + 1024, 512))
+        assert len(seen) == len(set(seen)) and min(seen) == 0 and max(seen) == 3 * world * 1024 - 512
