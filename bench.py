@@ -37,8 +37,10 @@ B_SLOT = 7 * 16 + 4 * 16         # shade kernel: slot state read (7 records) + w
 
 def cpu_baseline(pkg, scene, rays_per_path_ref, budget_s=20.0):
     """Time the reference's Render::render on the host cores over a bounded sample of the same workload."""
-    ncores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+    # the GPU box exposes every host core in the affinity mask but a 1-GPU job's CPU share is 16 cores; the reference's
+    # OpenMP loop also serialises on one shared mt19937 (utils.h:23-28), so more threads than that only add contention
+    ncores = min(16, len(os.sched_getaffinity(0)))
+    os.environ["OMP_NUM_THREADS"] = str(ncores)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     try:

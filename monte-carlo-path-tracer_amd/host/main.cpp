@@ -1,0 +1,112 @@
+// mcpt_cli -- headless replacement for the reference's GLFW shell (src/main.cpp:4-39): load a scene, render N frames
+// (= spp), print the reference's per-frame line, save <name><frames>.png.  `--gpus N` shards the sample range over N
+// devices of this node from ONE process and sums the films with RCCL (ncclAllReduce over xGMI).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include "Render.h"
+
+static void usage() {
+    std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
+                 "                          [--deterministic] [--ref-index-order]\n";
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { usage(); return 2; }
+    std::string filename = argv[1], out;
+    uint32_t spp = 64, batch = 0, depth = 0, gpus = 1; uint64_t seed = 20251004; uint32_t flags = 0, integrator = 0; bool ref_order = false, check_only = false;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i]; auto next = [&]() { return i + 1 < argc ? argv[++i] : (char*)"0"; };
+        if (a == "--spp") spp = uint32_t(std::atoi(next())); else if (a == "--batch") batch = uint32_t(std::atoi(next()));
+        else if (a == "--depth") depth = uint32_t(std::atoi(next())); else if (a == "--gpus") gpus = uint32_t(std::atoi(next()));
+        else if (a == "--out") out = next(); else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
+        else if (a == "--recursive") integrator = MCPT_INTEGRATOR_RECURSIVE_NEE; else if (a == "--corrected") flags |= MCPT_FLAG_CORRECT_SHADOW_T2;
+        else if (a == "--deterministic") flags |= MCPT_FLAG_DETERMINISTIC; else if (a == "--ref-index-order") ref_order = true;
+        else if (a == "--check") check_only = true;
+        else { usage(); return 2; }
+    }
+    Model model(filename, ref_order);
+    if (!model.ok) { std::cerr << "Error: scene did not load" << std::endl; return 1; }
+    std::cout << model.face.size() << " " << model.normal.size() << " " << model.vertex.size() << std::endl;   // main.cpp:14
+    if (check_only) {   // host-only: what the loader produced + what the library's flatten / BVH build makes of it (no GPU needed)
+        std::vector<mcpt_material> mats; std::vector<mcpt_texture> texs; mcpt_scene_desc d; mcpt_scene_info info;
+        model_to_desc(model, mats, texs, d);
+        const mcpt_status st = mcpt_check_scene(&d, &info);
+        double sv = 0, sn = 0, st_ = 0; long long sf = 0; double stex = 0;
+        for (auto& v : model.vertex) sv += v.x + 2 * v.y + 3 * v.z;
+        for (auto& v : model.normal) sn += v.x + 2 * v.y + 3 * v.z;
+        for (auto& v : model.texture) st_ += v.x + 2 * v.y;
+        for (auto& f : model.face) for (int i = 0; i < 3; i++) sf += f[i][0] + 3LL * f[i][1] + 5LL * f[i][2] + 7LL * f[i][3];
+        for (auto& m : model.materials) for (auto& c : m.Map_Kd->image_color) stex += c.x + c.y + c.z;
+        std::printf("{\"status\": %d, \"faces\": %zu, \"materials\": %zu, \"width\": %d, \"height\": %d, \"fovy\": %.17g, \"sum_v\": %.17g, \"sum_vn\": %.17g, "
+                    "\"sum_vt\": %.17g, \"sum_f\": %lld, \"sum_tex\": %.9g, \"n_tris\": %u, \"n_lights\": %u, \"n_nodes\": %u, \"bvh_depth\": %u}\n",
+                    int(st), model.face.size(), model.materials.size(), model.camerainfo.width, model.camerainfo.height, model.camerainfo.fovy, sv, sn, st_, sf, stex,
+                    info.n_tris, info.n_lights, info.n_nodes, info.bvh_depth);
+        return st == MCPT_OK ? 0 : 1;
+    }
+    const int w = model.camerainfo.width, h = model.camerainfo.height;
+    Scene scene(w, h);
+    const size_t slash = filename.rfind('/');
+    const std::string file_name = filename.substr(slash == std::string::npos ? 0 : slash + 1);
+    if (out.empty()) out = file_name;
+    if (batch == 0) batch = spp;
+    if (gpus < 1) gpus = 1;
+
+    std::vector<Render*> renders(gpus, nullptr);
+    for (uint32_t g = 0; g < gpus; g++) {
+        mcpt_opts o; std::memset(&o, 0, sizeof o); o.struct_size = sizeof o; o.device = int32_t(g); o.max_depth = depth; o.flags = flags; o.integrator = integrator;
+        renders[g] = new Render(model, o); renders[g]->seed = seed;
+        if (!renders[g]->ok()) return 1;
+    }
+    std::vector<ncclComm_t> comms(gpus);
+    if (gpus > 1) {
+        std::vector<int> devs(gpus); for (uint32_t g = 0; g < gpus; g++) devs[g] = int(g);
+        if (ncclCommInitAll(comms.data(), int(gpus), devs.data()) != ncclSuccess) { std::cerr << "Error: ncclCommInitAll" << std::endl; return 1; }
+    }
+    uint32_t frame = 0; uint64_t rays = 0; double total_s = 0;
+    std::vector<float> film(size_t(w) * h * 4);
+    while (frame < spp) {
+        const uint32_t n = std::min(batch, spp - frame);
+        auto t0 = std::chrono::steady_clock::now();
+        // sample range [frame, frame+n) split contiguously over the devices; one host thread per device (mcpt_render blocks
+        // until its device's work is enqueued and nearly finished)
+        std::vector<std::thread> th;
+        for (uint32_t g = 0; g < gpus; g++) th.emplace_back([&, g]() {
+            const uint32_t lo = frame + uint32_t(uint64_t(n) * g / gpus), hi = frame + uint32_t(uint64_t(n) * (g + 1) / gpus);
+            mcpt_ctx* c = renders[g]->handle();
+            mcpt_clear_accum(c);
+            if (hi > lo && mcpt_render(c, hi - lo, seed, lo) != MCPT_OK) std::cerr << "Error: " << mcpt_last_error() << std::endl;
+            mcpt_sync(c);
+        });
+        for (auto& t : th) t.join();
+        if (gpus > 1) {                               // the path's one exchange step: sum of the per-device films over xGMI
+            ncclGroupStart();
+            for (uint32_t g = 0; g < gpus; g++) {
+                void* p = nullptr; mcpt_accum_device_ptr(renders[g]->handle(), &p);
+                (void)hipSetDevice(int(g));
+                ncclAllReduce(p, p, size_t(w) * h * 4, ncclFloat, ncclSum, comms[g], nullptr);
+            }
+            ncclGroupEnd();
+            for (uint32_t g = 0; g < gpus; g++) { (void)hipSetDevice(int(g)); (void)hipDeviceSynchronize(); }
+        }
+        mcpt_read_accum(renders[0]->handle(), film.data());
+        scene.add_film(film.data());
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        total_s += s; frame += n;
+        std::cout << "frame: " << frame << "    frame cost: " << s << "s\n";                       // main.cpp:31
+    }
+    for (uint32_t g = 0; g < gpus; g++) { mcpt_counters c; mcpt_get_counters(renders[g]->handle(), &c); rays += c.rays_primary + c.rays_continuation + c.rays_shadow; }
+    std::printf("%u spp, %dx%d, %u GPU(s): %.3f s, %.1f Mray/s\n", spp, w, h, gpus, total_s, rays / total_s / 1e6);
+    scene.save_image(int(frame), out);                                                              // main.cpp:37
+    for (auto r : renders) delete r;
+    return 0;
+}
