@@ -26,17 +26,20 @@
 #define MCPT_STACK_DEPTH 32        // LDS traversal stack entries per lane (BVH builder guarantees depth <= this)
 #endif
 #define MCPT_BLOCK 256             // threads per workgroup = 4 waves of 64
+#define MCPT_TOP_NODES 1024        // nodes numbered breadth-first by the builder; the trace kernel serves them from LDS
 #define MCPT_NODE_SENTINEL ((int)0x80000000)
 
 struct DevMaterial {               // Material (model.h:32-40) + its Texture header (model.h:21-30)
     float ks[3]; float ns;
     float radiance[3]; uint32_t flags;       // MAT_*
     int32_t tex_off, tex_w, tex_h, pad;      // texel offset into DevScene::texels (float4 per texel)
+    float kd[3]; float pad2;                 // the colour of a 1x1 (constant) texture, so shading needs no texel fetch
 };
 #define MAT_HAS_SPEC   1u   // glm::length(Ks) != 0                (BSDF.cpp:96)
 #define MAT_MIRROR     2u   // ... and Ns >= 10000                 (BSDF.cpp:98)
 #define MAT_EMISSIVE   4u   // glm::length(radiance) != 0          (Triangle.cpp:75, Render.cpp:146)
 #define MAT_EMIT_0     8u   // glm::length(radiance) > 0.0001      (Render.cpp:121)
+#define MAT_CONST_KD  32u   // Map_Kd is a constant colour
 #define MAT_EMIT_REC  16u   // glm::length(radiance) > 0.01        (Render.cpp:94, light list :41)
 
 struct DevLight {                  // one entry of Render::lights (Render.cpp:41-42)

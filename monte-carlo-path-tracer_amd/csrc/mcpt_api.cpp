@@ -41,7 +41,7 @@ struct mcpt_ctx {
     bool use_wavefront = true;
     PathPool pool{};
     std::vector<DevBuf> pool_bufs;
-    DevBuf ctl_buf;
+    DevBuf ctl_buf, ovf_buf;
     IterCtl* h_ctl = nullptr;          // pinned ring of control-block snapshots (termination check)
     std::vector<hipEvent_t> chk_ev;
     std::vector<hipEvent_t> k_ev;      // per-kernel event chain (only with detailed timing)
@@ -73,7 +73,7 @@ void destroy_ctx(mcpt_ctx* c) {
     c->nodes.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_face.free_();
     c->mats.free_(); c->lights.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
     for (auto& b : c->pool_bufs) b.free_();
-    c->ctl_buf.free_();
+    c->ctl_buf.free_(); c->ovf_buf.free_();
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     for (auto e : c->chk_ev) (void)hipEventDestroy(e);
     for (auto e : c->k_ev) (void)hipEventDestroy(e);
@@ -179,7 +179,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         if (P < 2048) P = 2048;
         c->pool.P = P;
         c->tune.refill_at = env_u32("MCPT_WF_REFILL", 20); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 24);
-        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 40); c->tune.chunk = env_u32("MCPT_WF_CHUNK", 256);
+        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 8); c->tune.chunk = env_u32("MCPT_WF_CHUNK", 256);
         c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0) != 0;
         (void)pixels;
         if (c->use_wavefront) {
@@ -199,6 +199,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             for (auto& ev : c->chk_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
             c->trace_grid = uint32_t(c->n_cus) * uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0));
             c->trace_grid = env_u32("MCPT_WF_GRID", c->trace_grid);
+            if ((e = c->ovf_buf.alloc(size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_levels() * sizeof(int))) != hipSuccess) return bail(e, "alloc stack overflow area");
         }
     }
     if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "sync after upload");
@@ -313,7 +314,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p) {
         HIP_TRY(k_event());
         HIP_TRY(launch_wf_shade(ctx->dev, p, pool, ctl, it, n_items, ctx->accum, cnt, ctx->stream));
         HIP_TRY(k_event());
-        HIP_TRY(launch_wf_trace(ctx->dev, pool, ctl, it, ctx->tune, count, cnt, ctx->trace_grid, ctx->stream));
+        HIP_TRY(launch_wf_trace(ctx->dev, pool, ctl, it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(ctx->ovf_buf.p), ctx->stream));
         it++;
         if (it % CHECK == 0) {
             mcpt_status ps = poll(checks_issued - checks_seen >= 2); if (ps != MCPT_OK) return ps;   // host runs at most 2 checks (8 iterations) ahead
@@ -345,7 +346,7 @@ mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t fir
         // auto: long enough that per-item overheads (film atomics, tail of an item) vanish, short enough that there are
         // many more items than lanes/slots so the work balances across the chip
         spi = 64;
-        const uint64_t want_items = ctx->use_wavefront ? 4ull * ctx->pool.P / 64 : 256ull * 16 * 16;
+        const uint64_t want_items = ctx->use_wavefront ? 16ull * ctx->pool.P / 64 : 256ull * 16 * 16;   // >= 16 items per slot: short ramp-down tail
         while (spi > 8 && tiles * ((spp + spi - 1) / spi) < want_items) spi >>= 1;
         if (spi > spp) spi = spp;
     }

@@ -20,11 +20,15 @@ DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
-DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+// Division / normalisation of CONTINUOUS shading quantities: v_rcp_f32 / v_rsq_f32 (1 ulp) instead of the ~10-instruction IEEE
+// sequence hipcc emits for `/` -- the reference divides, but a 1-ulp difference here moves a pixel by ~1e-7 relative.  The few
+// operations whose last bit decides a branch of the reference (sample_light) use IEEE ops explicitly, see there.
+DEV float rcp(float s) { return __builtin_amdgcn_rcpf(s); }
+DEV f3 operator/(f3 a, float s) { const float r = rcp(s); return mk3(a.x * r, a.y * r, a.z * r); }
 DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-DEV float length(f3 a) { return sqrtf(dot(a, a)); }
-DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }          // glm: v * inversesqrt(dot(v,v))
+DEV float length(f3 a) { return __builtin_amdgcn_sqrtf(dot(a, a)); }
+DEV f3 normalize(f3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }   // glm: v * inversesqrt(dot(v,v))
 DEV float max3(f3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
 
 DEV d3 mkd(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -36,8 +40,15 @@ DEV d3 cross(d3 a, d3 b) { return mkd(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a
 DEV f3 to_f3(d3 a) { return mk3((float)a.x, (float)a.y, (float)a.z); }
 DEV d3 to_d3(f3 a) { return mkd((double)a.x, (double)a.y, (double)a.z); }
 DEV d3 ld_d3(const double* p) { return mkd(p[0], p[1], p[2]); }
+// fp64 reciprocal / reciprocal square root: hardware seed (v_rcp_f64 / v_rsq_f64) + two Newton steps = full double accuracy to
+// ~1 ulp in ~8 instructions instead of the ~30-instruction IEEE divide / sqrt sequences.  Every consumer compares against
+// quantities that differ at the 1e-8 level (SURVEY A-9) or rounds to fp32, so the last fp64 ulp is irrelevant.
+DEV double rcp64(double x) { double r = __builtin_amdgcn_rcp(x); r = fma(fma(-x, r, 1.0), r, r); r = fma(fma(-x, r, 1.0), r, r); return r; }
+DEV double rsq64(double x) { double r = __builtin_amdgcn_rsq(x); r = fma(fma(-0.5 * x * r, r, 0.5), r, r); r = fma(fma(-0.5 * x * r, r, 0.5), r, r); return r; }
 
 #define PT_PI 3.1415926f                       // utils.h:20 -- the reference's truncated pi, used in all shading
+#define PT_INV_PI (1.0f / 3.1415926f)
+#define PT_INV_2PI (1.0f / (2.0f * 3.1415926f))
 
 // ---------------------------------------------------------------------------------------------- RNG
 // Counter-based replacement for the reference's global mt19937 (utils.h:23-28): pcg4d (Jarzynski & Olano 2020)
@@ -64,7 +75,7 @@ DEV void cast_ray(const DevCamera& c, int x, int y, float xi_x, float xi_y, d3& 
     double dx = c.front[0] + u * c.right[0] + v * c.up[0];
     double dy = c.front[1] + u * c.right[1] + v * c.up[1];
     double dz = c.front[2] + u * c.right[2] + v * c.up[2];
-    double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+    double inv = rsq64(dx * dx + dy * dy + dz * dz);
     d = mk3((float)(dx * inv), (float)(dy * inv), (float)(dz * inv));
     o64 = mkd(c.eye[0], c.eye[1], c.eye[2]);
     o = to_f3(o64);
@@ -178,7 +189,7 @@ DEV d3 hit_point64(const DevScene& sc, int tri, d3 o64, f3 dir, float& u_out, fl
     const d3 v0 = ld_d3(P), v1 = ld_d3(P + 3), v2 = ld_d3(P + 6);
     const d3 e1 = v1 - v0, e2 = v2 - v0, dd = to_d3(dir);
     const d3 h = cross(dd, e2);
-    const double inv_a = 1.0 / dot(e1, h);
+    const double inv_a = rcp64(dot(e1, h));
     const d3 s = o64 - v0;
     const double u = dot(s, h) * inv_a;
     const d3 q = cross(s, e1);
@@ -194,6 +205,7 @@ DEV float tri_area(const DevScene& sc, int tri) {
 }
 // Texture::get_color (model.cpp:30-41) + clamp01 (utils.h:30-34): nearest texel, fract + 0.999 cap, no v flip
 DEV f3 tex_color(const DevScene& sc, const DevMaterial& m, float tu, float tv, uint32_t& texel_fetches) {
+    if (m.flags & MAT_CONST_KD) return mk3(m.kd[0], m.kd[1], m.kd[2]);      // Texture(Color3f): image_color.size() == 1 (model.cpp:32-35)
     int idx = m.tex_off;
     if (m.tex_w * m.tex_h != 1) {
         float fu = tu - floorf(tu), fv = tv - floorf(tv);
@@ -240,7 +252,7 @@ DEV Bsdf make_bsdf(const DevMaterial& m, f3 kd_tex, f3 n, f3 wi_world) {
     const float lum_s = b.ks.x * 0.212671f + b.ks.y * 0.715160f + b.ks.z * 0.072169f;
     const float sum = (b.kind == BSDF_DIFFUSE) ? lum_d : (lum_s + lum_d);
     b.w_spec = 0.f; b.w_diff = 0.f;                    // sum == 0: reference leaves weights uninitialised (A-12) -> path ends
-    if (sum != 0.f) { const float inv = 1.0f / sum; b.w_spec = lum_s * inv; b.w_diff = lum_d * inv; }
+    if (sum != 0.f) { const float inv = rcp(sum); b.w_spec = lum_s * inv; b.w_diff = lum_d * inv; }
     const f3 tot = b.kd + b.ks;                         // energy_conservation (BSDF.cpp:188-202)
     const float maxc = max3(tot);
     if (!(maxc < 1.0f)) { b.kd = b.kd / maxc; b.ks = b.ks / maxc; }
@@ -250,19 +262,19 @@ DEV Bsdf make_bsdf(const DevMaterial& m, f3 kd_tex, f3 n, f3 wi_world) {
 DEV f3 phong_fx(const Bsdf& b, f3 wi) {
     if (wi.z < 0.f || b.m_wo.z < 0.f) return mk3(0.f, 0.f, 0.f);
     const f3 H = normalize(wi + b.m_wo);
-    const float factor = (b.ns + 2.0f) / (2.f * PT_PI);
-    return b.ks * factor * powf(H.z, b.ns);
+    const float factor = (b.ns + 2.0f) * PT_INV_2PI;
+    return b.ks * factor * __powf(H.z, b.ns);
 }
 DEV float phong_pdf(const Bsdf& b, f3 wi) {
     if (b.m_wo.z < 0.f || wi.z < 0.f) return 0.f;
     const f3 H = normalize(wi + b.m_wo);
-    return (b.ns + 1.0f) / (2.f * PT_PI) * powf(H.z, b.ns);
+    return (b.ns + 1.0f) * PT_INV_2PI * __powf(H.z, b.ns);
 }
-DEV float diffuse_pdf(const Bsdf& b, f3 wi) { return (wi.z < 0.f || b.m_wo.z < 0.f) ? 0.f : (wi.z / PT_PI); }   // BSDF.cpp:28-31
+DEV float diffuse_pdf(const Bsdf& b, f3 wi) { return (wi.z < 0.f || b.m_wo.z < 0.f) ? 0.f : (wi.z * PT_INV_PI); }   // BSDF.cpp:28-31
 // BSDF::Fx (BSDF.cpp:112-121) and BSDF::Pdf (:153-163) for a world direction; Diffuse::Fx has no hemisphere test (A-22)
 DEV void bsdf_eval(const Bsdf& b, f3 dir_world, f3& fx, float& pdf) {
     const f3 wo = to_local(b, dir_world);
-    fx = b.kd / PT_PI;
+    fx = b.kd * PT_INV_PI;
     pdf = diffuse_pdf(b, wo) * b.w_diff;
     if (b.kind == BSDF_PHONG) { fx = phong_fx(b, wo) + fx; pdf = phong_pdf(b, wo) * b.w_spec + pdf; }
 }
@@ -278,11 +290,10 @@ DEV Scatter bsdf_sample(const Bsdf& b, float xi_lobe, float xi1, float xi2) {
         if (!(b.m_wo.z < 0.f)) {
             const float phi = xi1 * 2.f * PT_PI;
             const float theta = 0.5f * acosf(1.f - 2.f * xi2);
-            float st, ct, sp, cp;
-            sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
+            const float st = __sinf(theta), ct = __cosf(theta), sp = __sinf(phi), cp = __cosf(phi);
             s.wo = mk3(st * cp, st * sp, ct);
-            s.f = b.kd / PT_PI;
-            s.pdf = fabsf(ct) / PT_PI;
+            s.f = b.kd * PT_INV_PI;
+            s.pdf = fabsf(ct) * PT_INV_PI;
         }
         s.pdf *= b.w_diff;
         if (b.kind == BSDF_PHONG) { s.f = s.f + phong_fx(b, s.wo); s.pdf += phong_pdf(b, s.wo) * b.w_spec; }
@@ -290,18 +301,18 @@ DEV Scatter bsdf_sample(const Bsdf& b, float xi_lobe, float xi1, float xi2) {
     } else if (b.kind == BSDF_PHONG) {
         if (!(b.m_wo.z < 0.f)) {
             const float phi = 2.f * PT_PI * xi1;
-            const float cosT = powf(xi2, 1.f / (b.ns + 1.f));
-            const float sinT = sqrtf(1.f - cosT * cosT);
-            float sp, cp; sincosf(phi, &sp, &cp);
+            const float cosT = __powf(xi2, rcp(b.ns + 1.f));
+            const float sinT = __builtin_amdgcn_sqrtf(fmaxf(1.f - cosT * cosT, 0.f));
+            const float sp = __sinf(phi), cp = __cosf(phi);
             const f3 H = mk3(sinT * cp, sinT * sp, cosT);
             const f3 wi = -b.m_wo + H * 2.f * dot(H, b.m_wo);
             if (!(wi.z < 0.f)) {
                 s.wo = wi; s.f = phong_fx(b, wi);
-                s.pdf = (b.ns + 1.f) / (2.f * PT_PI) * powf(cosT, b.ns);
+                s.pdf = (b.ns + 1.f) * PT_INV_2PI * __powf(cosT, b.ns);
             }
         }
         s.pdf *= b.w_spec;
-        s.f = s.f + b.kd / PT_PI;                                        // other lobe: Diffuse::Fx(wo), no test
+        s.f = s.f + b.kd * PT_INV_PI;                                    // other lobe: Diffuse::Fx(wo), no test
         s.pdf += diffuse_pdf(b, s.wo) * b.w_diff;
     } else {                                                             // mirror
         if (!(b.m_wo.z < 0.f)) {
@@ -310,55 +321,72 @@ DEV Scatter bsdf_sample(const Bsdf& b, float xi_lobe, float xi1, float xi2) {
             s.pdf = 1.f; s.mirror = true;
         }
         s.pdf *= b.w_spec;
-        s.f = s.f + b.kd / PT_PI;
+        s.f = s.f + b.kd * PT_INV_PI;
         s.pdf += diffuse_pdf(b, s.wo) * b.w_diff;
     }
     s.wo = to_world(b, s.wo);
     return s;
 }
 
-DEV float power_heuristic(float p1, float p2) { const float s = p1 * p1 + p2 * p2; return s == 0.f ? 0.f : p1 * p1 / s; }   // utils.h:56-60
+DEV float power_heuristic(float p1, float p2) { const float s = p1 * p1 + p2 * p2; return s == 0.f ? 0.f : p1 * p1 * rcp(s); }   // utils.h:56-60
 
 // ---------------------------------------------------------------------------------------------- light sampling
 struct LightSample { f3 wo, rad; float pdf, t2; int tri; bool self_hit; };
+// The light pick depends only on a random number, so its record and fp64 corners can be requested as soon as the path's
+// RNG key is known -- light_fetch() is issued together with the hit's shading loads (one memory round trip, not two).
+struct LightData { float4 a, b, c, e; d3 v0, v1, v2; };   // a..e = the 64-B DevLight record
+DEV LightData light_fetch(const DevScene& sc, float xi_l) {
+    const int cnt = sc.n_lights;
+    int idx = (int)(xi_l * (float)cnt); idx = idx < cnt - 1 ? idx : cnt - 1;          // Render.cpp:204-205
+    const float4* L = reinterpret_cast<const float4*>(sc.lights + idx);
+    LightData d;
+    d.a = L[0]; d.b = L[1]; d.c = L[2]; d.e = L[3];
+    const double* P = sc.tri_pos64 + 9 * (size_t)__float_as_int(d.a.x);
+    d.v0 = ld_d3(P); d.v1 = ld_d3(P + 3); d.v2 = ld_d3(P + 6);
+    return d;
+}
 // Render::sample (Render.cpp:202-223) [guard = true] / the sampling half of sample_light (:177-200) [guard = false].
 // The light point is interpolated in fp64 and rounded to fp32 exactly like `vec3 point = light->interplote_Vertex(..)`.
 // self_hit = Triangle::isIntersect (Triangle.cpp:83-106) of the SAMPLED triangle against the shadow ray in fp64 with the
 // reference's inclusive t <= t2 = float(|d|): the rounding-level self-occlusion of SURVEY A-9.
-DEV LightSample sample_light(const DevScene& sc, d3 p64, float xi_l, float xi_u, float xi_v, bool guard) {
-    const int cnt = sc.n_lights;
-    int idx = (int)(xi_l * (float)cnt); idx = idx < cnt - 1 ? idx : cnt - 1;
-    const DevLight& lt = sc.lights[idx];
+DEV LightSample sample_light(const LightData& ld, d3 p64, float xi_u, float xi_v, bool guard) {
+    // DevLight layout: tri, area, radiance[3], n0[3], n1[3], n2[3], pad  ->  a = {tri, area, r, g}  b = {b, n0x, n0y, n0z}  c = {n1x, n1y, n1z, n2x}  e = {n2y, n2z, pad, -}
+    const int ltri = __float_as_int(ld.a.x); const float area = ld.a.y;
+    const f3 rad = mk3(ld.a.z, ld.a.w, ld.b.x);
+    const f3 n0 = mk3(ld.b.y, ld.b.z, ld.b.w), n1 = mk3(ld.c.x, ld.c.y, ld.c.z), n2 = mk3(ld.c.w, ld.e.x, ld.e.y);
     float u = xi_u, v = xi_v;
     if (u + v > 1.f) { u = 1.f - u; v = 1.f - v; }                      // Triangle.cpp:15-22
-    const double* P = sc.tri_pos64 + 9 * (size_t)lt.tri;
-    const d3 v0 = ld_d3(P), v1 = ld_d3(P + 3), v2 = ld_d3(P + 6);
+    const d3 v0 = ld.v0, v1 = ld.v1, v2 = ld.v2;
     const double b1 = (double)u, b2 = (double)v;
     const f3 point = to_f3((1.0 - b1 - b2) * v0 + b1 * v1 + b2 * v2);
     const float w = 1.f - u - v;
-    const f3 normal = normalize(mk3(w * lt.n0[0] + u * lt.n1[0] + v * lt.n2[0], w * lt.n0[1] + u * lt.n1[1] + v * lt.n2[1],
-                                    w * lt.n0[2] + u * lt.n1[2] + v * lt.n2[2]));
+    const f3 normal = normalize(mk3(w * n0.x + u * n1.x + v * n2.x, w * n0.y + u * n1.y + v * n2.y, w * n0.z + u * n1.z + v * n2.z));
     // The next five values feed the fp64 self-hit predicate below, whose verdict hangs on their LAST BIT (SURVEY A-9): they are
     // computed with the reference's exact rounding sequence (glm: products and sums rounded one by one, (x*x + y*y) + z*z,
-    // v * (1 / sqrt(dot)); Render.cpp:208-213,217) -- the _rn intrinsics keep hipcc from fusing them into FMAs, which would
-    // shift the self-occlusion rate (measured: image 1.2 % darker than the reference with contraction on).
+    // v * (1 / sqrt(dot)); Render.cpp:208-213,217): contraction is switched off for this block and sqrt / divide are IEEE.
     const f3 po = to_f3(p64);
-    const f3 d = mk3(__fsub_rn(point.x, po.x), __fsub_rn(point.y, po.y), __fsub_rn(point.z, po.z));
-    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(d.x, d.x), __fmul_rn(d.y, d.y)), __fmul_rn(d.z, d.z));
-    const float inv_len = __fdiv_rn(1.0f, __fsqrt_rn(d2));
-    const f3 dir = mk3(__fmul_rn(d.x, inv_len), __fmul_rn(d.y, inv_len), __fmul_rn(d.z, inv_len));
+    f3 d, dir; float d2, t2;
+    {
+#pragma clang fp contract(off)
+        d = mk3(point.x - po.x, point.y - po.y, point.z - po.z);
+        d2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
+        const float len = __builtin_sqrtf(d2);             // IEEE (correctly rounded) sqrt and divide: hipcc default for sqrtf and `/`
+        const float inv_len = 1.0f / len;
+        dir = mk3(d.x * inv_len, d.y * inv_len, d.z * inv_len);
+        t2 = len;
+    }
     const float cs = dot(-dir, normal);
     LightSample ls;
     ls.pdf = 0.f;
-    if (!guard || cs != 0.f) ls.pdf = d2 / cs / lt.area;
-    ls.wo = dir; ls.rad = mk3(lt.radiance[0], lt.radiance[1], lt.radiance[2]); ls.t2 = __fsqrt_rn(d2); ls.tri = lt.tri;
+    if (!guard || cs != 0.f) ls.pdf = d2 * rcp(cs) * rcp(area);
+    ls.wo = dir; ls.rad = rad; ls.t2 = t2; ls.tri = ltri;
     // fp64 Moller-Trumbore any-hit on the sampled triangle only
     const d3 e1 = v1 - v0, e2 = v2 - v0, dd = to_d3(dir);
     const d3 h = cross(dd, e2);
     const double det = dot(e1, h);
     bool self = false;
     if (!(fabs(det) < 1e-6)) {
-        const double inv = 1.0 / det;
+        const double inv = rcp64(det);
         const d3 s = p64 - v0;
         const double uu = inv * dot(s, h);
         if (!(uu < 0.0 || uu > 1.0)) {
@@ -372,4 +400,7 @@ DEV LightSample sample_light(const DevScene& sc, d3 p64, float xi_l, float xi_u,
     }
     ls.self_hit = self;
     return ls;
+}
+DEV LightSample sample_light(const DevScene& sc, d3 p64, float xi_l, float xi_u, float xi_v, bool guard) {
+    return sample_light(light_fetch(sc, xi_l), p64, xi_u, xi_v, guard);
 }

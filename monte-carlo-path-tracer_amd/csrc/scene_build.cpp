@@ -179,6 +179,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         if (rl > 0.0001) dm.flags |= MAT_EMIT_0;
         if (rl > 0.01) dm.flags |= MAT_EMIT_REC;
         dm.tex_off = tex_off[m.map_kd]; dm.tex_w = d->textures[m.map_kd].width; dm.tex_h = d->textures[m.map_kd].height;
+        if (dm.tex_w * dm.tex_h == 1) { dm.flags |= MAT_CONST_KD; for (int k = 0; k < 3; k++) dm.kd[k] = d->textures[m.map_kd].rgb[k]; }
         out.mats.push_back(dm);
     }
 
@@ -205,6 +206,35 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     Builder b(bt, out.nodes);
     b.run();
     out.bvh_depth = b.depth; out.max_leaf = b.max_leaf;
+    {   // Renumber: the first MCPT_TOP_NODES nodes in breadth-first order (= the top ~10 levels, which the trace kernel keeps in
+        // LDS), every subtree below them in depth-first order (children next to parents -> cache-line locality in L1/L2).
+        const int n_nodes = int(out.nodes.size() / 4);
+        std::vector<int> new_id(n_nodes, -1), order_new; order_new.reserve(n_nodes);
+        auto child = [&](int n, int k) { int c; std::memcpy(&c, k == 0 ? &out.nodes[4 * size_t(n) + 3].x : &out.nodes[4 * size_t(n) + 3].y, 4); return c; };
+        std::vector<int> queue{0}; size_t qh = 0;
+        while (qh < queue.size() && int(order_new.size()) + int(queue.size() - qh) <= MCPT_TOP_NODES) {
+            const int n = queue[qh++]; new_id[n] = int(order_new.size()); order_new.push_back(n);
+            for (int k = 0; k < 2; k++) { const int c = child(n, k); if (c >= 0) queue.push_back(c); }
+        }
+        std::vector<int> stack;
+        for (size_t i = queue.size(); i-- > qh;) stack.push_back(queue[i]);           // remaining frontier, in BFS order
+        while (!stack.empty()) {
+            const int n = stack.back(); stack.pop_back();
+            new_id[n] = int(order_new.size()); order_new.push_back(n);
+            const int c0 = child(n, 0), c1 = child(n, 1);
+            if (c1 >= 0) stack.push_back(c1);
+            if (c0 >= 0) stack.push_back(c0);
+        }
+        std::vector<f4h> renum(out.nodes.size());
+        for (int i = 0; i < n_nodes; i++) {
+            const int o = order_new[i];
+            for (int q = 0; q < 4; q++) renum[4 * size_t(i) + q] = out.nodes[4 * size_t(o) + q];
+            const int c0 = child(o, 0), c1 = child(o, 1);
+            renum[4 * size_t(i) + 3].x = as_float(c0 >= 0 ? new_id[c0] : c0);
+            renum[4 * size_t(i) + 3].y = as_float(c1 >= 0 ? new_id[c1] : c1);
+        }
+        out.nodes.swap(renum);
+    }
     out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (out.bvh_depth > uint32_t(MCPT_STACK_DEPTH - 1)) { err = "BVH depth exceeds traversal stack"; return MCPT_ERR_BVH_DEPTH; }
     const std::vector<int>& order = b.order();

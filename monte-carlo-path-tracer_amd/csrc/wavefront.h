@@ -29,6 +29,7 @@ struct PathPool {
 #define WF_SHARDS 8          // shadow-queue shards (block b appends to shard b % 8: 8x less contention on the cursor)
 #define WF_COUNTER_REPLICAS 1024
 #define WF_ITEM_SHARDS 64
+#define WF_LDS_MATS 64        // material tables up to this size are staged in LDS by the shade kernel (256 threads x 16 B = 64 x 64 B)
 
 struct IterCtl {        // indexed [iteration & 3]; shade(it) zeroes entry (it+1)&3 for the next iteration
     uint32_t trace_head[4];
@@ -55,5 +56,7 @@ struct WaveTuning {     // scheduler thresholds of the trace kernel (lanes out o
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
                            float4* accum, DevCounters* cnt, hipStream_t stream);
 hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,
-                           DevCounters* cnt, uint32_t grid_blocks, hipStream_t stream);
+                           DevCounters* cnt, uint32_t grid_blocks, int* stack_overflow, hipStream_t stream);
 int wf_trace_blocks_per_cu(bool count);
+uint32_t wf_trace_block_threads();
+uint32_t wf_trace_overflow_levels();

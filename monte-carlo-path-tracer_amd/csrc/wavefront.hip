@@ -17,6 +17,31 @@
 #include "pt_device.h"
 #include "wavefront.h"
 
+// Path-pool traffic is pure streaming (every record is read once and written once per iteration, ~1 GB per iteration): it is
+// issued NON-TEMPORAL so it does not evict the few MB of scene data (BVH, triangles) that every ray and every shaded hit
+// gathers from out of L2 / Infinity Cache.
+typedef float wf_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int wf_v4u __attribute__((ext_vector_type(4)));
+typedef double wf_v2d __attribute__((ext_vector_type(2)));
+#ifndef MCPT_NO_NT
+__device__ __forceinline__ float4 ld_s(const float4* p) { const wf_v4f v = __builtin_nontemporal_load(reinterpret_cast<const wf_v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st_s(float4* p, float4 v) { wf_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<wf_v4f*>(p)); }
+__device__ __forceinline__ uint4 ld_s(const uint4* p) { const wf_v4u v = __builtin_nontemporal_load(reinterpret_cast<const wf_v4u*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st_s(uint4* p, uint4 v) { wf_v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<wf_v4u*>(p)); }
+__device__ __forceinline__ double4 ld_s(const double4* p) {
+    const wf_v2d a = __builtin_nontemporal_load(reinterpret_cast<const wf_v2d*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const wf_v2d*>(p) + 1);
+    return make_double4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void st_s(double4* p, double4 v) {
+    wf_v2d a, b; a.x = v.x; a.y = v.y; b.x = v.z; b.y = v.w;
+    __builtin_nontemporal_store(a, reinterpret_cast<wf_v2d*>(p)); __builtin_nontemporal_store(b, reinterpret_cast<wf_v2d*>(p) + 1);
+}
+__device__ __forceinline__ uint32_t ld_s(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_s(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ __forceinline__ T ld_s(const T* p) { return *p; }
+template <class T> __device__ __forceinline__ void st_s(T* p, T v) { *p = v; }
+#endif
 __device__ __forceinline__ f3 xyz(const float4 v) { return mk3(v.x, v.y, v.z); }
 __device__ __forceinline__ float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 __device__ __forceinline__ f3 wf_scrub_nan(f3 c) {        // Scene::set_Pixel (Scene.cpp:16-18)
@@ -31,8 +56,11 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {            // num
 __device__ __forceinline__ uint32_t wave_first(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ====================================================================================================== shade
+#ifndef MCPT_SHADE_MIN_WAVES
+#define MCPT_SHADE_MIN_WAVES 1
+#endif
 template <bool COUNT>
-__global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, RenderParams p, PathPool pool, IterCtl* ctl, uint32_t it, uint32_t n_items,
+__global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_kernel(DevScene sc, RenderParams p, PathPool pool, IterCtl* ctl, uint32_t it, uint32_t n_items,
                                                               float4* __restrict__ accum, DevCounters* gcnt) {
     const uint32_t slot = blockIdx.x * MCPT_BLOCK + threadIdx.x;           // pool.P is a multiple of MCPT_BLOCK
     const uint32_t lane = threadIdx.x & 63;
@@ -40,17 +68,20 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
     __shared__ uint32_t s_wave_cnt[MCPT_BLOCK / 64];
     __shared__ uint32_t s_base, s_sel;
 
-    const float4 bt = pool.beta[slot];
+    const float4 bt = ld_s(&pool.beta[slot]);
     const uint32_t st = __float_as_uint(bt.w);
     uint32_t state = st & 3u;
     bool prev_mirror = (st & 4u) != 0;
     int bounce = (int)(st >> 8);
     f3 beta = xyz(bt);
-    const float4 Lp = pool.L[slot];
+    const float4 Lp = ld_s(&pool.L[slot]);
     f3 L = xyz(Lp);
     float prev_pdf = Lp.w;
-    uint4 id = pool.ids[slot];                                              // pixel, sample, s_next, s_end
-    float4 sm = pool.sum[slot];
+    uint4 id = ld_s(&pool.ids[slot]);                                              // pixel, sample, s_next, s_end
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f); bool sm_loaded = false;    // item accumulator: fetched only when a path ends
+    // one batch of requests for everything an ALIVE slot needs about its traced ray (nearly every slot is ALIVE in steady state)
+    float4 h = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f), ro4 = h, rd4 = h; double4 og = make_double4(0, 0, 0, 0);
+    if (state == SLOT_ALIVE) { h = ld_s(&pool.hit[slot]); ro4 = ld_s(&pool.ray_o[slot]); rd4 = ld_s(&pool.ray_d[slot]); og = ld_s(&pool.org64[slot]); }
     const float nl = (float)sc.n_lights;
     const bool correct_t2 = (p.flags & MCPT_FLAG_CORRECT_SHADOW_T2) != 0;
 
@@ -62,13 +93,15 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
     float sh_t2 = 0.f; int sh_skip = -1;
 
     if (state == SLOT_ALIVE) do {
-        const float4 h = pool.hit[slot];
         const int tri = __float_as_int(h.x);
         if (tri < 0) { terminated = true; break; }                                             // Render.cpp:118-119,144-145
         float hu, hv;
-        const f3 prev_p = xyz(pool.ray_o[slot]), d = xyz(pool.ray_d[slot]);
-        const double4 og = pool.org64[slot];                                                    // fp64 origin of the traced ray
-        const d3 p64 = hit_point64(sc, tri, mkd(og.x, og.y, og.z), d, hu, hv);
+        const f3 prev_p = xyz(ro4), d = xyz(rd4);
+        // second batch: the light record + its fp64 corners are requested NOW (they depend only on the RNG key), together with
+        // the hit triangle's fp64 corners and shading record below -- one memory round trip instead of two
+        const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
+        const LightData ld = light_fetch(sc, ra.v[0]);
+        const d3 p64 = hit_point64(sc, tri, mkd(og.x, og.y, og.z), d, hu, hv);               // og = fp64 origin of the traced ray
         const f3 p32 = to_f3(p64);
         const HitShade hs = load_hit_shade(sc, tri, hu, hv, d);
         const DevMaterial& mat = sc.mats[hs.mat];
@@ -82,7 +115,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
                     const float len = length(dd);
                     const float cosine = dot(normalize(dd), hs.n);
                     float light_pdf = 0.f;
-                    if (cosine != 0.f) light_pdf = len * len / cosine / nl / tri_area(sc, tri);
+                    if (cosine != 0.f) light_pdf = len * len * rcp(cosine * nl * tri_area(sc, tri));
                     L = L + beta * rad * power_heuristic(prev_pdf, light_pdf);
                 }
             }
@@ -98,17 +131,16 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
 
         const f3 kd = tex_color(sc, mat, hs.tu, hs.tv, c_texel);
         const Bsdf bsdf = make_bsdf(mat, kd, hs.n, -d);
-        const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
         const Rng4 rb = rng_block(id.x, id.y, 2u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
-        const LightSample ls = sample_light(sc, p64, ra.v[0], ra.v[1], ra.v[2], true);         // Render.cpp:124
+        const LightSample ls = sample_light(ld, p64, ra.v[1], ra.v[2], true);                  // Render.cpp:124
         if (ls.pdf != 0.f) {
             c_self_t = true; c_self_h = ls.self_hit;
             if (correct_t2 || !ls.self_hit) {
                 f3 fx; float bpdf;
                 bsdf_eval(bsdf, ls.wo, fx, bpdf);
                 const float cos_theta = fabsf(dot(hs.n, ls.wo));
-                const float weight = power_heuristic(ls.pdf / nl, bpdf);
-                nee = weight * beta * ls.rad * fx * cos_theta / ls.pdf * nl;                    // Render.cpp:127-129
+                const float weight = power_heuristic(ls.pdf * rcp(nl), bpdf);
+                nee = weight * beta * ls.rad * fx * (cos_theta * rcp(ls.pdf) * nl);                 // Render.cpp:127-129
                 sh_dir = ls.wo; sh_t2 = ls.t2; sh_skip = ls.tri; emit_shadow = true;
             }
         }
@@ -119,13 +151,14 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
             break;
         }
         const float cos_theta = fabsf(dot(hs.n, s.wo));
-        beta = beta * (s.f * cos_theta / s.pdf);                                                // Render.cpp:140
+        beta = beta * (s.f * (cos_theta * rcp(s.pdf)));                                         // Render.cpp:140
         prev_pdf = s.pdf; prev_mirror = s.mirror;
         nd = s.wo; bounce++;
         emit_extend = true; c_cont = true;
     } while (0);
     else if (state == SLOT_DRAIN) terminated = true;
 
+    if (terminated || (state == SLOT_DEAD && id.z == id.w)) { sm = ld_s(&pool.sum[slot]); sm_loaded = true; }
     if (terminated) {                                                                           // Scene::set_Pixel, per sample
         const f3 c = wf_scrub_nan(L);
         sm.x += c.x; sm.y += c.y; sm.z += c.z; sm.w += 1.f; sum_dirty = true;
@@ -196,14 +229,14 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
     }
 
     // ---- write the slot back
-    pool.beta[slot] = mk4(beta, __uint_as_float(state | (prev_mirror ? 4u : 0u) | ((uint32_t)bounce << 8)));
-    pool.L[slot] = mk4(L, prev_pdf);
-    if (emit_extend || emit_shadow) pool.ray_o[slot] = mk4(no, __int_as_float(sh_skip));
-    pool.ray_d[slot] = mk4(nd, emit_extend ? 1.f : 0.f);
-    if (emit_extend) pool.org64[slot] = make_double4(no64.x, no64.y, no64.z, 0.0);
-    if (emit_shadow) { pool.sh_d[slot] = mk4(sh_dir, sh_t2); pool.nee[slot] = mk4(nee, 0.f); }
-    if (sum_dirty) pool.sum[slot] = sm;
-    if (id_dirty) pool.ids[slot] = id;
+    st_s(&pool.beta[slot], mk4(beta, __uint_as_float(state | (prev_mirror ? 4u : 0u) | ((uint32_t)bounce << 8))));
+    st_s(&pool.L[slot], mk4(L, prev_pdf));
+    if (emit_extend || emit_shadow) st_s(&pool.ray_o[slot], mk4(no, __int_as_float(sh_skip)));
+    st_s(&pool.ray_d[slot], mk4(nd, emit_extend ? 1.f : 0.f));
+    if (emit_extend) st_s(&pool.org64[slot], make_double4(no64.x, no64.y, no64.z, 0.0));
+    if (emit_shadow) { st_s(&pool.sh_d[slot], mk4(sh_dir, sh_t2)); st_s(&pool.nee[slot], mk4(nee, 0.f)); }
+    if (sum_dirty && sm_loaded) st_s(&pool.sum[slot], sm);
+    if (id_dirty) st_s(&pool.ids[slot], id);
 
     // ---- shadow queue append: ranks inside the block through LDS, ONE atomic per block on the block's shard cursor
     const uint32_t cur = it & 3, wv = threadIdx.x >> 6, shard = blockIdx.x & (WF_SHARDS - 1);
@@ -218,7 +251,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
     if (emit_shadow) {
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
-        pool.shadow_queue[shard * pool.shard_cap + s_base + before + lane_rank(ms)] = slot;
+        st_s(&pool.shadow_queue[shard * pool.shard_cap + s_base + before + lane_rank(ms)], slot);
     }
     // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
     const uint64_t ma = __ballot(state != SLOT_DEAD);
@@ -242,10 +275,31 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_shade_kernel(DevScene sc, Rende
 // ====================================================================================================== trace
 // BVH_node::hit / has_hit (BVH.cpp:95-136), AABB::Intersection (AABB.cpp:25-36), Triangle::hit / isIntersect
 // (Triangle.cpp:48-106) for the whole ray list of one iteration.  Acceptance rules: see bvh_traverse in pt_device.h.
+// Block = WF_TRACE_BLOCK (1024) threads = 16 waves sharing one LDS image of the top MCPT_TOP_NODES nodes (64 KB, quarter-major so
+// that lanes reading different nodes spread over the banks) + a 16-entry per-lane stack (64 KB); deeper stack entries (rare)
+// spill to a global overflow area.  One block per CU: 16 waves / CU.
+#define WF_TRACE_BLOCK 1024
+#define WF_LDS_STACK 16
 template <bool COUNT>
-__global__ void __launch_bounds__(MCPT_BLOCK) wf_trace_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt) {
-    __shared__ int s_stack[MCPT_STACK_DEPTH * MCPT_BLOCK];
-    int* stk = s_stack + threadIdx.x;
+__global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
+                                                                  int* __restrict__ stack_overflow) {
+    __shared__ int s_stack[WF_LDS_STACK * WF_TRACE_BLOCK];
+    __shared__ float4 s_top[4 * MCPT_TOP_NODES];                      // [quarter][node]
+    // explicit address spaces: with generic pointers hipcc folds `lds ? : global` into ONE flat_load (select of pointers), which is
+    // slower than either path and hides the LDS traffic from the LDS pipe -- typed pointers keep ds_read / global_load apart
+    typedef __attribute__((address_space(3))) int lds_i32;
+    typedef float v4f __attribute__((ext_vector_type(4)));             // native vector: loads through typed pointers compile
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    typedef __attribute__((address_space(1))) int glb_i32;
+    typedef __attribute__((address_space(1))) const v4f glb_cf4;
+    lds_i32* stk = (lds_i32*)s_stack + threadIdx.x;
+    lds_f4* top = (lds_f4*)s_top;
+    const uint32_t ovf_stride = gridDim.x * WF_TRACE_BLOCK;
+    glb_i32* ovf = (glb_i32*)stack_overflow + (blockIdx.x * WF_TRACE_BLOCK + threadIdx.x);
+    glb_cf4* gnodes = (glb_cf4*)sc.nodes;
+    const int n_top = sc.n_nodes < MCPT_TOP_NODES ? sc.n_nodes : MCPT_TOP_NODES;
+    for (int i = threadIdx.x; i < 4 * n_top; i += WF_TRACE_BLOCK) s_top[(i & 3) * MCPT_TOP_NODES + (i >> 2)] = sc.nodes[i];
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = pool.P;
     uint32_t sh_end[WF_SHARDS];            // exclusive prefix ends of the shadow shards in the ray list (uniform -> SGPRs)
@@ -257,8 +311,8 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_trace_kernel(DevScene sc, PathP
     uint32_t* head = &ctl->trace_head[it & 3];
 
     // wave-private slice of the ray list: the first chunk is assigned statically (no atomic), later ones come from `head`
-    const uint32_t n_waves = gridDim.x * (MCPT_BLOCK / 64);
-    uint32_t w_next = (blockIdx.x * (MCPT_BLOCK / 64) + (threadIdx.x >> 6)) * tune.chunk;
+    const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
+    uint32_t w_next = (blockIdx.x * (WF_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) * tune.chunk;
     uint32_t w_end = min(w_next + tune.chunk, total);
     bool exhausted = false;
     if (w_next >= total) { w_next = w_end = 0; }
@@ -282,12 +336,12 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_trace_kernel(DevScene sc, PathP
             if (have && node == MCPT_NODE_SENTINEL) {                    // finished: write the result back
                 if (any) {
                     if (!blocked) {                                      // Render.cpp:125-130: unoccluded -> L += NEE term
-                        const float4 n4 = pool.nee[slot]; float4 l4 = pool.L[slot];
+                        const float4 n4 = ld_s(&pool.nee[slot]); float4 l4 = ld_s(&pool.L[slot]);
                         l4.x += n4.x; l4.y += n4.y; l4.z += n4.z;
-                        pool.L[slot] = l4;
+                        st_s(&pool.L[slot], l4);
                     }
                 } else {
-                    pool.hit[slot] = make_float4(__int_as_float(htri), hu, hv, ht);
+                    st_s(&pool.hit[slot], make_float4(__int_as_float(htri), hu, hv, ht));
                 }
                 have = false;
             }
@@ -306,15 +360,15 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_trace_kernel(DevScene sc, PathP
                         bool valid;
                         if (w < P) {                                     // extend ray of slot w
                             slot = w;
-                            const float4 rd = pool.ray_d[w];
+                            const float4 rd = ld_s(&pool.ray_d[w]);
                             valid = rd.w != 0.f;
-                            const float4 ro = pool.ray_o[w];
+                            const float4 ro = ld_s(&pool.ray_o[w]);
                             o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; skip = -1;
                         } else {                                         // shadow ray of a queued slot
                             uint32_t q = 0, lo = P;
                             for (int k = 0; k < WF_SHARDS - 1; k++) if (w >= sh_end[k]) { q = k + 1; lo = sh_end[k]; }
-                            slot = pool.shadow_queue[q * pool.shard_cap + (w - lo)];
-                            const float4 ro = pool.ray_o[slot], sd = pool.sh_d[slot];
+                            slot = ld_s(&pool.shadow_queue[q * pool.shard_cap + (w - lo)]);
+                            const float4 ro = ld_s(&pool.ray_o[slot]), sd = ld_s(&pool.sh_d[slot]);
                             o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; skip = __float_as_int(ro.w); valid = true;
                         }
                         if (valid) {
@@ -362,42 +416,56 @@ __global__ void __launch_bounds__(MCPT_BLOCK) wf_trace_kernel(DevScene sc, PathP
                     }
                 }
                 if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
-                else { sp--; node = stk[sp * MCPT_BLOCK]; }
+                else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
             }
             continue;
         }
 
-        // ---------------------------------------------------------------------- inner-node block
-        do {
-            if (have && node >= 0) {
-                const float4* n = sc.nodes + 4 * (size_t)node;
-                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-                const float c0x0 = fmaf(n0.x, idx, -oodx), c0x1 = fmaf(n0.y, idx, -oodx);
-                const float c0y0 = fmaf(n0.z, idy, -oody), c0y1 = fmaf(n0.w, idy, -oody);
-                const float c0z0 = fmaf(n2.x, idz, -oodz), c0z1 = fmaf(n2.y, idz, -oodz);
-                const float c1x0 = fmaf(n1.x, idx, -oodx), c1x1 = fmaf(n1.y, idx, -oodx);
-                const float c1y0 = fmaf(n1.z, idy, -oody), c1y1 = fmaf(n1.w, idy, -oody);
-                const float c1z0 = fmaf(n2.z, idz, -oodz), c1z1 = fmaf(n2.w, idz, -oodz);
-                const float c0n = fmaxf(fmaxf(fminf(c0x0, c0x1), fminf(c0y0, c0y1)), fmaxf(fminf(c0z0, c0z1), 1e-4f));
-                const float c0f = fminf(fminf(fmaxf(c0x0, c0x1), fmaxf(c0y0, c0y1)), fminf(fmaxf(c0z0, c0z1), tmax));
-                const float c1n = fmaxf(fmaxf(fminf(c1x0, c1x1), fminf(c1y0, c1y1)), fmaxf(fminf(c1z0, c1z1), 1e-4f));
-                const float c1f = fminf(fminf(fmaxf(c1x0, c1x1), fmaxf(c1y0, c1y1)), fminf(fmaxf(c1z0, c1z1), tmax));
-                const bool h0 = c0n <= c0f, h1 = c1n <= c1f;
-                if (COUNT) n_box += 2;
-                const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
-                if (h0 && h1) {
-                    const bool swp = c1n < c0n;
-                    node = swp ? ch1 : ch0;
-                    stk[sp * MCPT_BLOCK] = swp ? ch0 : ch1;
-#ifdef MCPT_EXPERIMENT_CLAMP_STACK
-                    if (sp < MCPT_STACK_DEPTH - 1)     // timing experiment only: drops entries on overflow (wrong image, safe memory)
-#endif
-                    sp++;
-                } else if (h0) node = ch0;
-                else if (h1) node = ch1;
-                else { sp--; node = stk[sp * MCPT_BLOCK]; }
-            }
-        } while (__popcll(__ballot(have && node >= 0)) >= (int)tune.inner_keep);
+        // ---------------------------------------------------------------------- inner-node blocks.  Two scheduling classes: nodes of
+        // the top levels are read from LDS, deeper ones from memory.  A vector-memory instruction costs the same TA issue time
+        // with 3 or with 60 active lanes, so the two classes run as separate blocks, each with well-packed lanes.
+#define WF_INNER_STEP()                                                                                                              \
+        {                                                                                                                            \
+            const float c0x0 = fmaf(n0.x, idx, -oodx), c0x1 = fmaf(n0.y, idx, -oodx);                                                \
+            const float c0y0 = fmaf(n0.z, idy, -oody), c0y1 = fmaf(n0.w, idy, -oody);                                                \
+            const float c0z0 = fmaf(n2.x, idz, -oodz), c0z1 = fmaf(n2.y, idz, -oodz);                                                \
+            const float c1x0 = fmaf(n1.x, idx, -oodx), c1x1 = fmaf(n1.y, idx, -oodx);                                                \
+            const float c1y0 = fmaf(n1.z, idy, -oody), c1y1 = fmaf(n1.w, idy, -oody);                                                \
+            const float c1z0 = fmaf(n2.z, idz, -oodz), c1z1 = fmaf(n2.w, idz, -oodz);                                                \
+            const float c0n = fmaxf(fmaxf(fminf(c0x0, c0x1), fminf(c0y0, c0y1)), fmaxf(fminf(c0z0, c0z1), 1e-4f));                   \
+            const float c0f = fminf(fminf(fmaxf(c0x0, c0x1), fmaxf(c0y0, c0y1)), fminf(fmaxf(c0z0, c0z1), tmax));                    \
+            const float c1n = fmaxf(fmaxf(fminf(c1x0, c1x1), fminf(c1y0, c1y1)), fmaxf(fminf(c1z0, c1z1), 1e-4f));                   \
+            const float c1f = fminf(fminf(fmaxf(c1x0, c1x1), fmaxf(c1y0, c1y1)), fminf(fmaxf(c1z0, c1z1), tmax));                    \
+            const bool h0 = c0n <= c0f, h1 = c1n <= c1f;                                                                             \
+            if (COUNT) n_box += 2;                                                                                                   \
+            const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);                                                        \
+            if (h0 && h1) {                                                                                                          \
+                const bool swp = c1n < c0n;                                                                                          \
+                node = swp ? ch1 : ch0;                                                                                              \
+                const int far = swp ? ch0 : ch1;                                                                                     \
+                if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = far; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = far;             \
+                sp++;                                                                                                                \
+            } else if (h0) node = ch0;                                                                                               \
+            else if (h1) node = ch1;                                                                                                 \
+            else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; } \
+        }
+        const int n_top = __popcll(__ballot(have && node >= 0 && node < MCPT_TOP_NODES));
+        if (2 * n_top >= n_inner) {
+            do {
+                if (have && node >= 0 && node < MCPT_TOP_NODES) {
+                    const v4f n0 = top[node], n1 = top[MCPT_TOP_NODES + node], n2 = top[2 * MCPT_TOP_NODES + node], n3 = top[3 * MCPT_TOP_NODES + node];
+                    WF_INNER_STEP()
+                }
+            } while (__popcll(__ballot(have && node >= 0 && node < MCPT_TOP_NODES)) >= (int)tune.inner_keep);
+        } else {
+            do {
+                if (have && node >= MCPT_TOP_NODES) {
+                    glb_cf4* n = gnodes + 4 * (size_t)node;
+                    const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                    WF_INNER_STEP()
+                }
+            } while (__popcll(__ballot(have && node >= MCPT_TOP_NODES)) >= (int)tune.inner_keep);
+        }
     }
 
     if (COUNT) {
@@ -416,15 +484,17 @@ hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const Path
     return hipGetLastError();
 }
 hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,
-                           DevCounters* cnt, uint32_t grid_blocks, hipStream_t stream) {
-    if (count) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(grid_blocks), dim3(MCPT_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt);
-    else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(grid_blocks), dim3(MCPT_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt);
+                           DevCounters* cnt, uint32_t grid_blocks, int* stack_overflow, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
+    else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
     return hipGetLastError();
 }
 int wf_trace_blocks_per_cu(bool count) {
     int n = 0;
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, MCPT_BLOCK, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<false>, MCPT_BLOCK, 0);
-    if (e != hipSuccess || n <= 0) n = 4;
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, WF_TRACE_BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<false>, WF_TRACE_BLOCK, 0);
+    if (e != hipSuccess || n <= 0) n = 1;
     return n;
 }
+uint32_t wf_trace_block_threads() { return WF_TRACE_BLOCK; }
+uint32_t wf_trace_overflow_levels() { return MCPT_STACK_DEPTH > WF_LDS_STACK ? MCPT_STACK_DEPTH - WF_LDS_STACK : 1; }
