@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, SPP, DEPTH = 800, 800, 1024, 8
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per unit of work with THIS build's layouts
-B_BOX, B_TRI = 32, 48            # half a 64-B two-child node per slab test; one 48-B {v0,e1,e2} record per triangle test
+B_BOX, B_TRI = 16, 48            # a quarter of a 64-B four-child node per slab test; one 48-B {v0,e1,e2} record per triangle test
 B_RAY = 32 + 16                  # trace kernel: ray fetch (origin + direction records) + 16-B result write-back per ray
 B_SHADED, B_TEXEL, B_LIGHT = 64 + 72, 16, 72 + 64     # shade kernel: shading record + fp64 corners; texel; light corners + light record
 B_SLOT = 7 * 16 + 4 * 16         # shade kernel: slot state read (7 records) + written back (4 records) per visited slot

@@ -56,8 +56,14 @@ struct DevCamera {                 // Render::cast_Ray's per-frame constants hoi
     int32_t width, height;
 };
 
+// nodes4: 64 B / node of the 4-wide quantised tree (breadth-first numbering):
+//   f4[0] = origin x y z (fp32) | u32: biased exponents ex | ey << 8 | ez << 16 | valid mask << 24
+//   f4[1] = u32 x4: qlo.x qlo.y qlo.z qhi.x   (byte k = child k, box = origin + q * 2^e, rounded outward)
+//   f4[2] = u32 x2: qhi.y qhi.z | 2 spare
+//   f4[3] = i32 x4: child codes (>= 0 inner node4 index, < 0 leaf ~(first << 3 | count); count 0 = empty)
 struct DevScene {
     const float4* nodes;
+    const float4* nodes4;
     const float4* tri_isect;
     const float4* tri_shade;
     const double* tri_pos64;
@@ -66,7 +72,7 @@ struct DevScene {
     const DevLight* lights;
     const float4* texels;
     DevCamera cam;
-    int32_t n_tris, n_lights, n_nodes, n_mats;
+    int32_t n_tris, n_lights, n_nodes, n_mats, n_nodes4;
 };
 
 struct RenderParams {

@@ -28,7 +28,7 @@ struct mcpt_ctx {
     int device = 0;
     mcpt_opts opts{};
     DevScene dev{};
-    DevBuf nodes, tri_isect, tri_shade, tri_pos64, tri_face, mats, lights, texels, accum_own, counters;
+    DevBuf nodes, nodes4, tri_isect, tri_shade, tri_pos64, tri_face, mats, lights, texels, accum_own, counters;
     float4* accum = nullptr;           // bound accumulator (own or external)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -39,18 +39,28 @@ struct mcpt_ctx {
     int width = 0, height = 0;
     // ---- wavefront pipeline (the default for MCPT_INTEGRATOR_MIS)
     bool use_wavefront = true;
-    PathPool pool{};
-    std::vector<DevBuf> pool_bufs;
-    DevBuf ctl_buf, ovf_buf;
-    IterCtl* h_ctl = nullptr;          // pinned ring of control-block snapshots (termination check)
-    std::vector<hipEvent_t> chk_ev;
-    std::vector<hipEvent_t> k_ev;      // per-kernel event chain (only with detailed timing)
+    // Sub-pipelines ("lanes"): each owns a path pool, a control block and a stream and runs its own [shade, trace] loop on its
+    // share of the sample range.  Two of them in flight let the issue-bound shade kernel of one overlap the memory-bound trace
+    // kernel of the other on the same CUs (measured +15 % on MI355X).
+    struct WfLane {
+        PathPool pool{};
+        std::vector<DevBuf> pool_bufs;
+        DevBuf ctl_buf, ovf_buf;
+        IterCtl* h_ctl = nullptr;          // pinned ring of control-block snapshots (termination check)
+        std::vector<hipEvent_t> chk_ev;
+        std::vector<hipEvent_t> k_ev;      // per-kernel event chain (only with detailed timing)
+        hipStream_t stream = nullptr;
+        hipEvent_t done_ev = nullptr;
+        uint64_t last_iterations = 0;
+    };
+    std::vector<WfLane> lanes;
+    hipEvent_t fork_ev = nullptr;
     WaveTuning tune{};
     uint32_t trace_grid = 0;
     int n_cus = 0;
     bool time_kernels = false;
     double last_trace_ms = 0.0, total_trace_ms = 0.0, last_shade_ms = 0.0, total_shade_ms = 0.0;
-    uint64_t last_iterations = 0, total_iterations = 0;
+    uint64_t total_iterations = 0;
 };
 
 namespace {
@@ -70,13 +80,18 @@ hipError_t upload(DevBuf& b, const std::vector<T>& v) {
 void destroy_ctx(mcpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    c->nodes.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_face.free_();
+    c->nodes.free_(); c->nodes4.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_face.free_();
     c->mats.free_(); c->lights.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
-    for (auto& b : c->pool_bufs) b.free_();
-    c->ctl_buf.free_(); c->ovf_buf.free_();
-    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
-    for (auto e : c->chk_ev) (void)hipEventDestroy(e);
-    for (auto e : c->k_ev) (void)hipEventDestroy(e);
+    for (auto& L : c->lanes) {
+        for (auto& b : L.pool_bufs) b.free_();
+        L.ctl_buf.free_(); L.ovf_buf.free_();
+        if (L.h_ctl) (void)hipHostFree(L.h_ctl);
+        for (auto e : L.chk_ev) (void)hipEventDestroy(e);
+        for (auto e : L.k_ev) (void)hipEventDestroy(e);
+        if (L.done_ev) (void)hipEventDestroy(L.done_ev);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -156,6 +171,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = upload(c->nodes, hs.nodes)) != hipSuccess) return bail(e, "upload nodes");
+    if ((e = upload(c->nodes4, hs.nodes4)) != hipSuccess) return bail(e, "upload nodes4");
     if ((e = upload(c->tri_isect, hs.tri_isect)) != hipSuccess) return bail(e, "upload tri_isect");
     if ((e = upload(c->tri_shade, hs.tri_shade)) != hipSuccess) return bail(e, "upload tri_shade");
     if ((e = upload(c->tri_pos64, hs.tri_pos64)) != hipSuccess) return bail(e, "upload tri_pos64");
@@ -177,36 +193,46 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         const uint64_t pixels = uint64_t(c->width) * c->height;
         uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 22);
         if (P < 2048) P = 2048;
-        c->pool.P = P;
-        c->tune.refill_at = env_u32("MCPT_WF_REFILL", 20); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 24);
-        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 8); c->tune.chunk = env_u32("MCPT_WF_CHUNK", 256);
+        c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 24);
+        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.chunk = env_u32("MCPT_WF_CHUNK", 256);
         c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0) != 0;
         (void)pixels;
         if (c->use_wavefront) {
-            c->pool_bufs.resize(11);
-            void** dst[11] = {(void**)&c->pool.ray_o, (void**)&c->pool.ray_d, (void**)&c->pool.hit, (void**)&c->pool.sh_d, (void**)&c->pool.nee,
-                              (void**)&c->pool.L, (void**)&c->pool.beta, (void**)&c->pool.sum, (void**)&c->pool.ids, (void**)&c->pool.shadow_queue,
-                              (void**)&c->pool.org64};
-            for (int i = 0; i < 11; i++) {
-                const size_t bytes = i == 9 ? (size_t(P) + WF_SHARDS * MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * (i == 10 ? 32 : 16);
-                if ((e = c->pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
-                if ((e = hipMemset(c->pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
-                *dst[i] = c->pool_bufs[i].p;
-            }
-            if ((e = c->ctl_buf.alloc(sizeof(IterCtl))) != hipSuccess) return bail(e, "alloc IterCtl");
-            if ((e = hipHostMalloc((void**)&c->h_ctl, 8 * sizeof(IterCtl), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
-            c->chk_ev.resize(8);
-            for (auto& ev : c->chk_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+            uint32_t n_lanes = env_u32("MCPT_WF_LANES", 2);
+            if (n_lanes < 1) n_lanes = 1;
+            if (o.flags & MCPT_FLAG_DETERMINISTIC) n_lanes = 1;          // one owner per pixel, plain stores
             c->trace_grid = uint32_t(c->n_cus) * uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0));
             c->trace_grid = env_u32("MCPT_WF_GRID", c->trace_grid);
-            if ((e = c->ovf_buf.alloc(size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_levels() * sizeof(int))) != hipSuccess) return bail(e, "alloc stack overflow area");
+            if ((e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+            c->lanes.resize(n_lanes);
+            for (auto& L : c->lanes) {
+                L.pool.P = P;
+                L.pool_bufs.resize(11);
+                void** dst[11] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sh_d, (void**)&L.pool.nee,
+                                  (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
+                                  (void**)&L.pool.org64};
+                for (int i = 0; i < 11; i++) {
+                    const size_t bytes = i == 9 ? (size_t(P) + WF_SHARDS * MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * (i == 10 ? 32 : 16);
+                    if ((e = L.pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
+                    if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
+                    *dst[i] = L.pool_bufs[i].p;
+                }
+                if ((e = L.ctl_buf.alloc(sizeof(IterCtl))) != hipSuccess) return bail(e, "alloc IterCtl");
+                if ((e = hipHostMalloc((void**)&L.h_ctl, 8 * sizeof(IterCtl), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+                L.chk_ev.resize(8);
+                for (auto& ev : L.chk_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+                if ((e = hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+                if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+                if ((e = L.ovf_buf.alloc(size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_levels(hs.bvh4_depth) * sizeof(int))) != hipSuccess)
+                    return bail(e, "alloc stack overflow area");
+            }
         }
     }
     if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "sync after upload");
     c->accum = static_cast<float4*>(c->accum_own.p);
 
     DevScene& d = c->dev;
-    d.nodes = static_cast<const float4*>(c->nodes.p); d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
+    d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes4 = static_cast<const float4*>(c->nodes4.p); d.n_nodes4 = int32_t(hs.nodes4.size() / 4); d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
     d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p);
     d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
     d.lights = static_cast<const DevLight*>(c->lights.p); d.texels = static_cast<const float4*>(c->texels.p);
@@ -216,9 +242,9 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     mcpt_scene_info& in = c->info;
     in.n_tris = uint32_t(d.n_tris); in.n_lights = uint32_t(d.n_lights); in.n_nodes = uint32_t(d.n_nodes);
     in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
-    in.device_bytes = c->nodes.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_face.bytes + c->mats.bytes +
+    in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_face.bytes + c->mats.bytes +
                       c->lights.bytes + c->texels.bytes + accum_bytes;
-    for (auto& b : c->pool_bufs) in.device_bytes += b.bytes;
+    for (auto& L : c->lanes) for (auto& b : L.pool_bufs) in.device_bytes += b.bytes;
     in.bvh_build_ms = hs.bvh_build_ms;
     in.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out_ctx = c;
@@ -246,89 +272,124 @@ static mcpt_status resolve_timing(mcpt_ctx* c) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->last_kernel_ms = ms; c->total_kernel_ms += ms; c->timing_pending = false;
         if (c->use_wavefront) {
-            c->total_iterations += c->last_iterations;
-            if (c->time_kernels && c->last_iterations) {
-                double sh = 0.0, tr = 0.0;
-                for (uint64_t i = 0; i < c->last_iterations; i++) {
-                    float a_ = 0.f, b_ = 0.f;
-                    HIP_TRY(hipEventElapsedTime(&a_, c->k_ev[2 * i], c->k_ev[2 * i + 1]));
-                    HIP_TRY(hipEventElapsedTime(&b_, c->k_ev[2 * i + 1], c->k_ev[2 * i + 2]));
-                    sh += a_; tr += b_;
-                }
-                c->last_shade_ms = sh; c->last_trace_ms = tr; c->total_shade_ms += sh; c->total_trace_ms += tr;
+            double sh = 0.0, tr = 0.0;
+            for (auto& L : c->lanes) {
+                c->total_iterations += L.last_iterations;
+                if (c->time_kernels)
+                    for (uint64_t i = 0; i < L.last_iterations; i++) {
+                        float a_ = 0.f, b_ = 0.f;
+                        HIP_TRY(hipEventElapsedTime(&a_, L.k_ev[2 * i], L.k_ev[2 * i + 1]));
+                        HIP_TRY(hipEventElapsedTime(&b_, L.k_ev[2 * i + 1], L.k_ev[2 * i + 2]));
+                        sh += a_; tr += b_;
+                    }
+                L.last_iterations = 0;
             }
+            c->last_shade_ms = sh; c->last_trace_ms = tr; c->total_shade_ms += sh; c->total_trace_ms += tr;
         }
     }
     return MCPT_OK;
 }
 
-static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p) {
-    // One mcpt_render call = a loop of [shade, trace] launches over the slot pool until every work item is finished.
-    const uint64_t tiles = uint64_t(p.tiles_x) * p.tiles_y;
-    const uint32_t n_items = uint32_t(tiles * 64 * p.chunks);
-    PathPool pool = ctx->pool;
-    const uint32_t want = uint32_t(((uint64_t(n_items) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
-    if (pool.P > want) pool.P = want;                                  // small jobs: do not sweep idle slots
-    pool.shard_cap = ((pool.P / MCPT_BLOCK + WF_SHARDS - 1) / WF_SHARDS) * MCPT_BLOCK;
-    IterCtl* ctl = static_cast<IterCtl*>(ctx->ctl_buf.p);
-    DevCounters* cnt = static_cast<DevCounters*>(ctx->counters.p);
-    HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(IterCtl), ctx->stream));
-    HIP_TRY(hipMemsetAsync(pool.beta, 0, size_t(pool.P) * 16, ctx->stream));    // every slot DEAD
-    HIP_TRY(hipMemsetAsync(pool.ids, 0, size_t(pool.P) * 16, ctx->stream));
-    HIP_TRY(hipMemsetAsync(pool.sum, 0, size_t(pool.P) * 16, ctx->stream));
-    const bool count = (p.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
+static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
+    // One mcpt_render call = per sub-pipeline a loop of [shade, trace] launches over its slot pool until its work items are done.
+    // The sample range is split contiguously over the sub-pipelines; their streams fork from and join the context's stream.
+    const uint64_t tiles = uint64_t(p0.tiles_x) * p0.tiles_y;
+    const uint32_t n_lanes = uint32_t(ctx->lanes.size());
+    const bool count = (p0.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
     const uint32_t CHECK = 4, RING = 8;
     const bool debug = env_u32("MCPT_WF_DEBUG", 0) != 0;
     const uint32_t max_it = env_u32("MCPT_WF_MAXIT", 1u << 20);
-    uint32_t it = 0, checks_issued = 0, checks_seen = 0;
-    size_t kev = 0;
-    bool done = false;
-    auto k_event = [&]() -> hipError_t {
+    DevCounters* cnt = static_cast<DevCounters*>(ctx->counters.p);
+    struct Run { RenderParams p; PathPool pool; uint32_t n_items = 0, it = 0, issued = 0, seen = 0; size_t kev = 0; bool active = false, done = false; };
+    std::vector<Run> runs(n_lanes);
+    uint32_t n_active = 0;
+    for (uint32_t k = 0; k < n_lanes; k++) {
+        Run& r = runs[k];
+        const uint32_t lo = uint32_t(uint64_t(p0.spp) * k / n_lanes), hi = uint32_t(uint64_t(p0.spp) * (k + 1) / n_lanes);
+        if (hi == lo) { r.done = true; ctx->lanes[k].last_iterations = 0; continue; }
+        r.p = p0; r.p.spp = hi - lo; r.p.first_sample = p0.first_sample + lo;
+        if (r.p.samples_per_item > r.p.spp) r.p.samples_per_item = r.p.spp;
+        r.p.chunks = (r.p.spp + r.p.samples_per_item - 1) / r.p.samples_per_item;
+        r.n_items = uint32_t(tiles * 64 * r.p.chunks);
+        r.pool = ctx->lanes[k].pool;
+        const uint32_t want = uint32_t(((uint64_t(r.n_items) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
+        if (r.pool.P > want) r.pool.P = want;                              // small jobs: do not sweep idle slots
+        r.pool.shard_cap = ((r.pool.P / MCPT_BLOCK + WF_SHARDS - 1) / WF_SHARDS) * MCPT_BLOCK;
+        r.active = true; n_active++;
+    }
+    for (Run& r : runs) if (r.active) r.p.atomic_accum = (n_active > 1 || r.p.chunks > 1) ? 1u : 0u;
+    HIP_TRY(hipEventRecord(ctx->fork_ev, ctx->stream));
+    for (uint32_t k = 0; k < n_lanes; k++) {
+        if (!runs[k].active) continue;
+        mcpt_ctx::WfLane& L = ctx->lanes[k]; Run& r = runs[k];
+        HIP_TRY(hipStreamWaitEvent(L.stream, ctx->fork_ev, 0));
+        HIP_TRY(hipMemsetAsync(L.ctl_buf.p, 0, sizeof(IterCtl), L.stream));
+        HIP_TRY(hipMemsetAsync(r.pool.beta, 0, size_t(r.pool.P) * 16, L.stream));    // every slot DEAD
+        HIP_TRY(hipMemsetAsync(r.pool.ids, 0, size_t(r.pool.P) * 16, L.stream));
+        HIP_TRY(hipMemsetAsync(r.pool.sum, 0, size_t(r.pool.P) * 16, L.stream));
+    }
+    auto k_event = [&](mcpt_ctx::WfLane& L, Run& r) -> hipError_t {
         if (!ctx->time_kernels) return hipSuccess;
-        if (kev == ctx->k_ev.size()) { hipEvent_t ev; hipError_t e = hipEventCreate(&ev); if (e != hipSuccess) return e; ctx->k_ev.push_back(ev); }
-        return hipEventRecord(ctx->k_ev[kev++], ctx->stream);
+        if (r.kev == L.k_ev.size()) { hipEvent_t ev; hipError_t e = hipEventCreate(&ev); if (e != hipSuccess) return e; L.k_ev.push_back(ev); }
+        return hipEventRecord(L.k_ev[r.kev++], L.stream);
     };
-    // consume finished control-block snapshots; `block` waits for the oldest one (ring full)
-    auto poll = [&](bool block) -> mcpt_status {
-        while (checks_seen < checks_issued) {
-            const uint32_t k = checks_seen % RING;
-            if (block) { HIP_TRY(hipEventSynchronize(ctx->chk_ev[k])); block = false; }
+    // consume finished control-block snapshots of one sub-pipeline; `block` waits for the oldest one
+    auto poll = [&](mcpt_ctx::WfLane& L, Run& r, bool block) -> mcpt_status {
+        while (r.seen < r.issued) {
+            const uint32_t k = r.seen % RING;
+            if (block) { HIP_TRY(hipEventSynchronize(L.chk_ev[k])); block = false; }
             else {
-                hipError_t q = hipEventQuery(ctx->chk_ev[k]);
+                hipError_t q = hipEventQuery(L.chk_ev[k]);
                 if (q == hipErrorNotReady) break;
                 if (q != hipSuccess) return hip_fail(q, "hipEventQuery");
             }
-            const IterCtl& s = ctx->h_ctl[k];
-            const uint32_t it_of = (checks_seen + 1) * CHECK - 1;      // snapshot taken after iteration it_of
-            if (debug && checks_seen < 40)
+            const IterCtl& s = L.h_ctl[k];
+            const uint32_t it_of = (r.seen + 1) * CHECK - 1;               // snapshot taken after iteration it_of
+            if (debug && r.seen < 40)
                 fprintf(stderr, "[wf] it=%u active=%u shadow0=%u head=%u cursor0=%u/%u\n", it_of, s.any_active[it_of & 3], s.n_shadow[it_of & 3][0],
-                        s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(n_items, 0));
+                        s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(r.n_items, 0));
             bool items_left = false;
-            for (uint32_t k = 0; k < WF_ITEM_SHARDS; k++) items_left |= s.item_cursor[k].v < wf_shard_capacity(n_items, k);
-            if (s.any_active[it_of & 3] == 0 && !items_left) done = true;
-            checks_seen++;
+            for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) items_left |= s.item_cursor[q].v < wf_shard_capacity(r.n_items, q);
+            if (s.any_active[it_of & 3] == 0 && !items_left) r.done = true;
+            r.seen++;
         }
         return MCPT_OK;
     };
-    while (!done) {
-        HIP_TRY(k_event());
-        HIP_TRY(launch_wf_shade(ctx->dev, p, pool, ctl, it, n_items, ctx->accum, cnt, ctx->stream));
-        HIP_TRY(k_event());
-        HIP_TRY(launch_wf_trace(ctx->dev, pool, ctl, it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(ctx->ovf_buf.p), ctx->stream));
-        it++;
-        if (it % CHECK == 0) {
-            mcpt_status ps = poll(checks_issued - checks_seen >= 2); if (ps != MCPT_OK) return ps;   // host runs at most 2 checks (8 iterations) ahead
-            if (done) break;
-            const uint32_t k = checks_issued % RING;
-            HIP_TRY(hipMemcpyAsync(&ctx->h_ctl[k], ctl, sizeof(IterCtl), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipEventRecord(ctx->chk_ev[k], ctx->stream));
-            checks_issued++;
+    bool all_done = n_active == 0;
+    while (!all_done) {
+        all_done = true;
+        for (uint32_t k = 0; k < n_lanes; k++) {                            // one iteration of every live sub-pipeline per round
+            Run& r = runs[k];
+            if (!r.active || r.done) continue;
+            mcpt_ctx::WfLane& L = ctx->lanes[k];
+            IterCtl* ctl = static_cast<IterCtl*>(L.ctl_buf.p);
+            HIP_TRY(k_event(L, r));
+            HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_items, ctx->accum, cnt, L.stream));
+            HIP_TRY(k_event(L, r));
+            HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(L.ovf_buf.p), L.stream));
+            r.it++;
+            if (r.it % CHECK == 0) {
+                mcpt_status ps = poll(L, r, r.issued - r.seen >= 2); if (ps != MCPT_OK) return ps;   // at most 2 checks (8 iterations) ahead
+                if (!r.done) {
+                    const uint32_t q = r.issued % RING;
+                    HIP_TRY(hipMemcpyAsync(&L.h_ctl[q], ctl, sizeof(IterCtl), hipMemcpyDeviceToHost, L.stream));
+                    HIP_TRY(hipEventRecord(L.chk_ev[q], L.stream));
+                    r.issued++;
+                }
+            }
+            if (!r.done) { mcpt_status ps = poll(L, r, false); if (ps != MCPT_OK) return ps; }
+            if (r.it > max_it) return fail(MCPT_ERR_HIP, "wavefront loop did not terminate within MCPT_WF_MAXIT iterations");
+            if (!r.done) all_done = false;
         }
-        mcpt_status ps = poll(false); if (ps != MCPT_OK) return ps;
-        if (it > max_it) return fail(MCPT_ERR_HIP, "wavefront loop did not terminate within MCPT_WF_MAXIT iterations");
     }
-    HIP_TRY(k_event());
-    ctx->last_iterations = it;
+    for (uint32_t k = 0; k < n_lanes; k++) {
+        if (!runs[k].active) continue;
+        mcpt_ctx::WfLane& L = ctx->lanes[k];
+        HIP_TRY(k_event(L, runs[k]));
+        L.last_iterations = runs[k].it;
+        HIP_TRY(hipEventRecord(L.done_ev, L.stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, L.done_ev, 0));            // join: the caller's stream continues after every sub-pipeline
+    }
     return MCPT_OK;
 }
 
@@ -346,7 +407,7 @@ mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t fir
         // auto: long enough that per-item overheads (film atomics, tail of an item) vanish, short enough that there are
         // many more items than lanes/slots so the work balances across the chip
         spi = 64;
-        const uint64_t want_items = ctx->use_wavefront ? 16ull * ctx->pool.P / 64 : 256ull * 16 * 16;   // >= 16 items per slot: short ramp-down tail
+        const uint64_t want_items = ctx->use_wavefront ? 16ull * ctx->lanes[0].pool.P * ctx->lanes.size() / 64 : 256ull * 16 * 16;   // >= 16 items per slot: short ramp-down tail
         while (spi > 8 && tiles * ((spp + spi - 1) / spi) < want_items) spi >>= 1;
         if (spi > spp) spi = spp;
     }

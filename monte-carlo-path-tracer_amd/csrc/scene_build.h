@@ -10,7 +10,8 @@
 struct f4h { float x, y, z, w; };   // host mirror of float4 (16 B)
 
 struct HostScene {
-    std::vector<f4h> nodes;          // 4 per inner node
+    std::vector<f4h> nodes;          // 4 per inner node (binary tree: megakernel + probes)
+    std::vector<f4h> nodes4;         // 4 per node of the 4-wide quantised tree (wavefront trace kernel)
     std::vector<f4h> tri_isect;      // 3 per triangle (leaf order)
     std::vector<f4h> tri_shade;      // 4 per triangle
     std::vector<double> tri_pos64;   // 9 per triangle
@@ -19,7 +20,7 @@ struct HostScene {
     std::vector<DevLight> lights;
     std::vector<f4h> texels;
     DevCamera cam;
-    uint32_t bvh_depth = 0, max_leaf = 0;
+    uint32_t bvh_depth = 0, max_leaf = 0, bvh4_depth = 0;
     double bvh_build_ms = 0.0;
 };
 

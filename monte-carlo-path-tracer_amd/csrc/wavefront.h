@@ -59,4 +59,4 @@ hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ct
                            DevCounters* cnt, uint32_t grid_blocks, int* stack_overflow, hipStream_t stream);
 int wf_trace_blocks_per_cu(bool count);
 uint32_t wf_trace_block_threads();
-uint32_t wf_trace_overflow_levels();
+uint32_t wf_trace_overflow_levels(uint32_t bvh4_depth);

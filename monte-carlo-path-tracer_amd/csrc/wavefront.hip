@@ -92,8 +92,17 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     d3 no64 = mkd(0, 0, 0);
     float sh_t2 = 0.f; int sh_skip = -1;
 
+#ifdef MCPT_EXPERIMENT_SHADE_NULL     // timing diagnostic: slot-state streaming + regeneration only, no hit processing (image is garbage)
+    if (state == SLOT_ALIVE) {
+        if (bounce >= 3 || __float_as_int(h.x) < 0) terminated = true;
+        else { no = xyz(ro4); nd = xyz(rd4); no64 = mkd(og.x, og.y, og.z); bounce++; emit_extend = true; c_cont = true; }
+    } else if (state == SLOT_DRAIN) terminated = true;
+    if (false) do {
+        const int tri = -1;
+#else
     if (state == SLOT_ALIVE) do {
         const int tri = __float_as_int(h.x);
+#endif
         if (tri < 0) { terminated = true; break; }                                             // Render.cpp:118-119,144-145
         float hu, hv;
         const f3 prev_p = xyz(ro4), d = xyz(rd4);
@@ -156,7 +165,9 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         nd = s.wo; bounce++;
         emit_extend = true; c_cont = true;
     } while (0);
+#ifndef MCPT_EXPERIMENT_SHADE_NULL
     else if (state == SLOT_DRAIN) terminated = true;
+#endif
 
     if (terminated || (state == SLOT_DEAD && id.z == id.w)) { sm = ld_s(&pool.sum[slot]); sm_loaded = true; }
     if (terminated) {                                                                           // Scene::set_Pixel, per sample
@@ -296,9 +307,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     lds_f4* top = (lds_f4*)s_top;
     const uint32_t ovf_stride = gridDim.x * WF_TRACE_BLOCK;
     glb_i32* ovf = (glb_i32*)stack_overflow + (blockIdx.x * WF_TRACE_BLOCK + threadIdx.x);
-    glb_cf4* gnodes = (glb_cf4*)sc.nodes;
-    const int n_top = sc.n_nodes < MCPT_TOP_NODES ? sc.n_nodes : MCPT_TOP_NODES;
-    for (int i = threadIdx.x; i < 4 * n_top; i += WF_TRACE_BLOCK) s_top[(i & 3) * MCPT_TOP_NODES + (i >> 2)] = sc.nodes[i];
+    glb_cf4* gnodes = (glb_cf4*)sc.nodes4;
+    const int n_top = sc.n_nodes4 < MCPT_TOP_NODES ? sc.n_nodes4 : MCPT_TOP_NODES;
+    for (int i = threadIdx.x; i < 4 * n_top; i += WF_TRACE_BLOCK) s_top[(i & 3) * MCPT_TOP_NODES + (i >> 2)] = sc.nodes4[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = pool.P;
@@ -421,51 +432,47 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
             continue;
         }
 
-        // ---------------------------------------------------------------------- inner-node blocks.  Two scheduling classes: nodes of
-        // the top levels are read from LDS, deeper ones from memory.  A vector-memory instruction costs the same TA issue time
-        // with 3 or with 60 active lanes, so the two classes run as separate blocks, each with well-packed lanes.
-#define WF_INNER_STEP()                                                                                                              \
-        {                                                                                                                            \
-            const float c0x0 = fmaf(n0.x, idx, -oodx), c0x1 = fmaf(n0.y, idx, -oodx);                                                \
-            const float c0y0 = fmaf(n0.z, idy, -oody), c0y1 = fmaf(n0.w, idy, -oody);                                                \
-            const float c0z0 = fmaf(n2.x, idz, -oodz), c0z1 = fmaf(n2.y, idz, -oodz);                                                \
-            const float c1x0 = fmaf(n1.x, idx, -oodx), c1x1 = fmaf(n1.y, idx, -oodx);                                                \
-            const float c1y0 = fmaf(n1.z, idy, -oody), c1y1 = fmaf(n1.w, idy, -oody);                                                \
-            const float c1z0 = fmaf(n2.z, idz, -oodz), c1z1 = fmaf(n2.w, idz, -oodz);                                                \
-            const float c0n = fmaxf(fmaxf(fminf(c0x0, c0x1), fminf(c0y0, c0y1)), fmaxf(fminf(c0z0, c0z1), 1e-4f));                   \
-            const float c0f = fminf(fminf(fmaxf(c0x0, c0x1), fmaxf(c0y0, c0y1)), fminf(fmaxf(c0z0, c0z1), tmax));                    \
-            const float c1n = fmaxf(fmaxf(fminf(c1x0, c1x1), fminf(c1y0, c1y1)), fmaxf(fminf(c1z0, c1z1), 1e-4f));                   \
-            const float c1f = fminf(fminf(fmaxf(c1x0, c1x1), fmaxf(c1y0, c1y1)), fminf(fmaxf(c1z0, c1z1), tmax));                    \
-            const bool h0 = c0n <= c0f, h1 = c1n <= c1f;                                                                             \
-            if (COUNT) n_box += 2;                                                                                                   \
-            const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);                                                        \
-            if (h0 && h1) {                                                                                                          \
-                const bool swp = c1n < c0n;                                                                                          \
-                node = swp ? ch1 : ch0;                                                                                              \
-                const int far = swp ? ch0 : ch1;                                                                                     \
-                if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = far; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = far;             \
-                sp++;                                                                                                                \
-            } else if (h0) node = ch0;                                                                                               \
-            else if (h1) node = ch1;                                                                                                 \
-            else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; } \
-        }
-        const int n_top = __popcll(__ballot(have && node >= 0 && node < MCPT_TOP_NODES));
-        if (2 * n_top >= n_inner) {
-            do {
-                if (have && node >= 0 && node < MCPT_TOP_NODES) {
-                    const v4f n0 = top[node], n1 = top[MCPT_TOP_NODES + node], n2 = top[2 * MCPT_TOP_NODES + node], n3 = top[3 * MCPT_TOP_NODES + node];
-                    WF_INNER_STEP()
+        // ---------------------------------------------------------------------- inner-node block: one 64-B record of the 4-wide tree
+        // = four child boxes, 8-bit offsets in the node's frame.  t = q * (2^e * idir) + (origin * idir - o * idir): two FMAs per
+        // plane after one v_cvt_f32_ubyteN.  Hit children are ordered by entry distance (5-comparator network); the nearest is
+        // visited next, the others go on the stack far-to-near.  Top levels come from LDS, the rest from memory.
+        do {
+            if (have && node >= 0) {
+                v4f A, B, C, D;
+                if (node < MCPT_TOP_NODES) { A = top[node]; B = top[MCPT_TOP_NODES + node]; C = top[2 * MCPT_TOP_NODES + node]; D = top[3 * MCPT_TOP_NODES + node]; }
+                else { glb_cf4* n = gnodes + 4 * (size_t)node; A = n[0]; B = n[1]; C = n[2]; D = n[3]; }
+                const uint32_t meta = __float_as_uint(A.w);
+                const float ax = __uint_as_float((meta & 0xffu) << 23) * idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy,
+                            az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
+                const float bx = fmaf(A.x, idx, -oodx), by = fmaf(A.y, idy, -oody), bz = fmaf(A.z, idz, -oodz);
+                const uint32_t qlx = __float_as_uint(B.x), qly = __float_as_uint(B.y), qlz = __float_as_uint(B.z), qhx = __float_as_uint(B.w),
+                               qhy = __float_as_uint(C.x), qhz = __float_as_uint(C.y);
+                const uint32_t valid = meta >> 24;
+                float key0, key1, key2, key3;
+#define WF_CHILD(K, KEY)                                                                                                             \
+                {                                                                                                                    \
+                    const float t0x = fmaf((float)((qlx >> (8 * K)) & 0xffu), ax, bx), t1x = fmaf((float)((qhx >> (8 * K)) & 0xffu), ax, bx); \
+                    const float t0y = fmaf((float)((qly >> (8 * K)) & 0xffu), ay, by), t1y = fmaf((float)((qhy >> (8 * K)) & 0xffu), ay, by); \
+                    const float t0z = fmaf((float)((qlz >> (8 * K)) & 0xffu), az, bz), t1z = fmaf((float)((qhz >> (8 * K)) & 0xffu), az, bz); \
+                    const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 1e-4f));                  \
+                    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));                   \
+                    KEY = (((valid >> K) & 1u) && tn <= tf) ? tn : __builtin_inff();                                                 \
                 }
-            } while (__popcll(__ballot(have && node >= 0 && node < MCPT_TOP_NODES)) >= (int)tune.inner_keep);
-        } else {
-            do {
-                if (have && node >= MCPT_TOP_NODES) {
-                    glb_cf4* n = gnodes + 4 * (size_t)node;
-                    const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-                    WF_INNER_STEP()
-                }
-            } while (__popcll(__ballot(have && node >= MCPT_TOP_NODES)) >= (int)tune.inner_keep);
-        }
+                WF_CHILD(0, key0) WF_CHILD(1, key1) WF_CHILD(2, key2) WF_CHILD(3, key3)
+#undef WF_CHILD
+                if (COUNT) n_box += (uint32_t)__popc(valid);
+                int cd0 = __float_as_int(D.x), cd1 = __float_as_int(D.y), cd2 = __float_as_int(D.z), cd3 = __float_as_int(D.w);
+#define WF_CSWAP(KA, CA, KB, CB) { const bool sw = KB < KA; const float tk = sw ? KB : KA; KB = sw ? KA : KB; KA = tk; const int tc = sw ? CB : CA; CB = sw ? CA : CB; CA = tc; }
+                WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2) WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
+#undef WF_CSWAP
+                const float inf = __builtin_inff();
+                if (key3 < inf) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd3; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd3; sp++; }
+                if (key2 < inf) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd2; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd2; sp++; }
+                if (key1 < inf) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd1; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd1; sp++; }
+                if (key0 < inf) node = cd0;
+                else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
+            }
+        } while (__popcll(__ballot(have && node >= 0)) >= (int)tune.inner_keep);
     }
 
     if (COUNT) {
@@ -497,4 +504,7 @@ int wf_trace_blocks_per_cu(bool count) {
     return n;
 }
 uint32_t wf_trace_block_threads() { return WF_TRACE_BLOCK; }
-uint32_t wf_trace_overflow_levels() { return MCPT_STACK_DEPTH > WF_LDS_STACK ? MCPT_STACK_DEPTH - WF_LDS_STACK : 1; }
+uint32_t wf_trace_overflow_levels(uint32_t bvh4_depth) {   // worst case: 3 deferred children per level of the 4-wide tree
+    const uint32_t need = 3 * bvh4_depth + 4;
+    return need > WF_LDS_STACK ? need - WF_LDS_STACK : 1;
+}
