@@ -156,8 +156,9 @@ def main():
                     "kernel": "wf_trace_kernel<false>", "kernel_ms": round(trace_ms, 4), "launches_per_step": round(launches / max(1, args.steps), 1),
                     "algorithmic_bytes_per_ray": round(trace_bytes_per_ray, 1),
                     "box_tests_per_ray": round(ci.box_tests / max(1, ci.rays), 2), "tri_tests_per_ray": round(ci.tri_tests / max(1, ci.rays), 2),
-                    "second_kernel": {"kernel": "wf_shade_kernel<false>", "kernel_ms": round(shade_ms, 4),
-                                      "share_of_step": round(c.shade_ms_total / max(1e-9, c.kernel_ms_total), 3)},
+                    "second_kernel": {"kernel": "wf_shade_kernel<false>", "kernel_ms": round(shade_ms, 4)},
+                    "concurrency": "two sub-pipelines run concurrently (shade of one overlaps trace of the other), so per-launch durations are "
+                                   "those of kernels sharing the GPU and their sum exceeds the step time",
                     "note": "algorithmic bytes of BVH traversal are mostly served by L1/L2 (scene = %.1f MB of nodes+triangles); the HBM "
                             "traffic of this kernel is the ray/hit stream of the path pool -- see DESIGN.md" % (
                                 (ri_info_nodes(r) * 64 + r.info().n_tris * 48) / 1e6)}
