@@ -16,12 +16,13 @@
 //   tri_shade  64 B / triangle   : n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y material
 //   tri_pos64  72 B / triangle   : v0 v1 v2 in fp64 -- read once per shaded hit to form the fp64 hit point the
 //                                  reference's shadow-ray self-occlusion depends on (SURVEY A-9), and per light sample
+//   tri_plane64 32 B / triangle  : fp64 plane (n.xyz, n.v0): the fp64 hit point of a shaded hit in two 16-B loads
 //   tri_face    4 B / triangle   : leaf order -> face index of the input (Model::face order)
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
-#define MCPT_LEAF_MAX 4
+#define MCPT_LEAF_MAX 2
 #ifndef MCPT_STACK_DEPTH
 #define MCPT_STACK_DEPTH 32        // LDS traversal stack entries per lane (BVH builder guarantees depth <= this)
 #endif
@@ -47,8 +48,9 @@ struct DevLight {                  // one entry of Render::lights (Render.cpp:41
     float area;                    // Triangle::area() (Triangle.cpp:24-28), fp32
     float radiance[3];
     float n0[3], n1[3], n2[3];     // vertex normals (fp32) for interplote_Normal
-    int32_t pad;
+    int32_t pad[2];                // 64 B: read as four 16-B records
 };
+static_assert(sizeof(DevLight) == 64 && sizeof(DevMaterial) == 64, "records are fetched as 4 x float4");
 
 struct DevCamera {                 // Render::cast_Ray's per-frame constants hoisted (Render.cpp:73-75), fp64
     double eye[3], front[3], right[3], up[3];
@@ -67,6 +69,7 @@ struct DevScene {
     const float4* tri_isect;
     const float4* tri_shade;
     const double* tri_pos64;
+    const double* tri_plane64;     // 4 doubles / triangle: n = (v1-v0) x (v2-v0) and n.v0, both fp64
     const int32_t* tri_face;
     const DevMaterial* mats;
     const DevLight* lights;

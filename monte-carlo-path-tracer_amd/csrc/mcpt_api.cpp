@@ -28,7 +28,7 @@ struct mcpt_ctx {
     int device = 0;
     mcpt_opts opts{};
     DevScene dev{};
-    DevBuf nodes, nodes4, tri_isect, tri_shade, tri_pos64, tri_face, mats, lights, texels, accum_own, counters;
+    DevBuf nodes, nodes4, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, texels, accum_own, counters;
     float4* accum = nullptr;           // bound accumulator (own or external)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -80,7 +80,7 @@ hipError_t upload(DevBuf& b, const std::vector<T>& v) {
 void destroy_ctx(mcpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    c->nodes.free_(); c->nodes4.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_face.free_();
+    c->nodes.free_(); c->nodes4.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_plane64.free_(); c->tri_face.free_();
     c->mats.free_(); c->lights.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
     for (auto& L : c->lanes) {
         for (auto& b : L.pool_bufs) b.free_();
@@ -175,6 +175,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if ((e = upload(c->tri_isect, hs.tri_isect)) != hipSuccess) return bail(e, "upload tri_isect");
     if ((e = upload(c->tri_shade, hs.tri_shade)) != hipSuccess) return bail(e, "upload tri_shade");
     if ((e = upload(c->tri_pos64, hs.tri_pos64)) != hipSuccess) return bail(e, "upload tri_pos64");
+    if ((e = upload(c->tri_plane64, hs.tri_plane64)) != hipSuccess) return bail(e, "upload tri_plane64");
     if ((e = upload(c->tri_face, hs.tri_face)) != hipSuccess) return bail(e, "upload tri_face");
     if ((e = upload(c->mats, hs.mats)) != hipSuccess) return bail(e, "upload materials");
     if ((e = upload(c->lights, hs.lights)) != hipSuccess) return bail(e, "upload lights");
@@ -207,12 +208,12 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             c->lanes.resize(n_lanes);
             for (auto& L : c->lanes) {
                 L.pool.P = P;
-                L.pool_bufs.resize(11);
-                void** dst[11] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sh_d, (void**)&L.pool.nee,
+                L.pool_bufs.resize(12);
+                void** dst[12] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sh_d, (void**)&L.pool.nee,
                                   (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
-                                  (void**)&L.pool.org64};
-                for (int i = 0; i < 11; i++) {
-                    const size_t bytes = i == 9 ? (size_t(P) + WF_SHARDS * MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * (i == 10 ? 32 : 16);
+                                  (void**)&L.pool.org64, (void**)&L.pool.shadow_count};
+                for (int i = 0; i < 12; i++) {
+                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 11 ? size_t(P / MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * (i == 10 ? 32 : 16);
                     if ((e = L.pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
                     if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
                     *dst[i] = L.pool_bufs[i].p;
@@ -233,7 +234,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
 
     DevScene& d = c->dev;
     d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes4 = static_cast<const float4*>(c->nodes4.p); d.n_nodes4 = int32_t(hs.nodes4.size() / 4); d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
-    d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p);
+    d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p); d.tri_plane64 = static_cast<const double*>(c->tri_plane64.p);
     d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
     d.lights = static_cast<const DevLight*>(c->lights.p); d.texels = static_cast<const float4*>(c->texels.p);
     d.cam = hs.cam;
@@ -242,7 +243,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     mcpt_scene_info& in = c->info;
     in.n_tris = uint32_t(d.n_tris); in.n_lights = uint32_t(d.n_lights); in.n_nodes = uint32_t(d.n_nodes);
     in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
-    in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_face.bytes + c->mats.bytes +
+    in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes + c->mats.bytes +
                       c->lights.bytes + c->texels.bytes + accum_bytes;
     for (auto& L : c->lanes) for (auto& b : L.pool_bufs) in.device_bytes += b.bytes;
     in.bvh_build_ms = hs.bvh_build_ms;
@@ -314,7 +315,6 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
         r.pool = ctx->lanes[k].pool;
         const uint32_t want = uint32_t(((uint64_t(r.n_items) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
         if (r.pool.P > want) r.pool.P = want;                              // small jobs: do not sweep idle slots
-        r.pool.shard_cap = ((r.pool.P / MCPT_BLOCK + WF_SHARDS - 1) / WF_SHARDS) * MCPT_BLOCK;
         r.active = true; n_active++;
     }
     for (Run& r : runs) if (r.active) r.p.atomic_accum = (n_active > 1 || r.p.chunks > 1) ? 1u : 0u;
@@ -346,7 +346,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
             const IterCtl& s = L.h_ctl[k];
             const uint32_t it_of = (r.seen + 1) * CHECK - 1;               // snapshot taken after iteration it_of
             if (debug && r.seen < 40)
-                fprintf(stderr, "[wf] it=%u active=%u shadow0=%u head=%u cursor0=%u/%u\n", it_of, s.any_active[it_of & 3], s.n_shadow[it_of & 3][0],
+                fprintf(stderr, "[wf] it=%u active=%u head=%u cursor0=%u/%u\n", it_of, s.any_active[it_of & 3],
                         s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(r.n_items, 0));
             bool items_left = false;
             for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) items_left |= s.item_cursor[q].v < wf_shard_capacity(r.n_items, q);

@@ -328,7 +328,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     for (uint32_t i = 0; i < nf; i++) pos_of_face[order[i]] = int(i);
 
     // ---- streams in leaf order
-    out.tri_isect.resize(3 * size_t(nf)); out.tri_shade.resize(4 * size_t(nf)); out.tri_pos64.resize(9 * size_t(nf)); out.tri_face.resize(nf);
+    out.tri_isect.resize(3 * size_t(nf)); out.tri_shade.resize(4 * size_t(nf)); out.tri_pos64.resize(9 * size_t(nf)); out.tri_plane64.resize(4 * size_t(nf)); out.tri_face.resize(nf);
     for (uint32_t i = 0; i < nf; i++) {
         const int f = order[i];
         const int32_t* c = d->face + 12 * size_t(f);
@@ -343,6 +343,12 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         out.tri_shade[4 * size_t(i) + 2] = {float(n2[0]), float(n2[1]), float(n2[2]), float(t1_[0])};
         out.tri_shade[4 * size_t(i) + 3] = {float(t1_[1]), float(t2_[0]), float(t2_[1]), as_float(c[3])};
         for (int a = 0; a < 3; a++) { out.tri_pos64[9 * size_t(i) + a] = v0[a]; out.tri_pos64[9 * size_t(i) + 3 + a] = v1[a]; out.tri_pos64[9 * size_t(i) + 6 + a] = v2[a]; }
+        {
+            const double ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2], bx = v2[0] - v0[0], by = v2[1] - v0[1], bz = v2[2] - v0[2];
+            const double nx = ay * bz - by * az, ny = az * bx - bz * ax, nz = ax * by - bx * ay;
+            double* pl = &out.tri_plane64[4 * size_t(i)];
+            pl[0] = nx; pl[1] = ny; pl[2] = nz; pl[3] = nx * v0[0] + ny * v0[1] + nz * v0[2];
+        }
         out.tri_face[i] = f;
     }
 

@@ -15,6 +15,7 @@ struct HostScene {
     std::vector<f4h> tri_isect;      // 3 per triangle (leaf order)
     std::vector<f4h> tri_shade;      // 4 per triangle
     std::vector<double> tri_pos64;   // 9 per triangle
+    std::vector<double> tri_plane64; // 4 per triangle
     std::vector<int32_t> tri_face;   // leaf order -> input face index
     std::vector<DevMaterial> mats;
     std::vector<DevLight> lights;

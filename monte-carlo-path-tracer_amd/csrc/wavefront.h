@@ -21,21 +21,21 @@ struct PathPool {
     float4* sum;        // item accumulator: sum of finished samples xyz | w: number of finished samples
     uint4* ids;         // pixel, current sample index, next sample index, end sample index
     double4* org64;     // fp64 origin of the extend ray (reference: Ray::start is a dvec3); read only by shade
-    uint32_t* shadow_queue;   // slots with a pending shadow ray: WF_SHARDS regions of shard_cap entries, appended by shade, consumed by trace
+    uint32_t* shadow_queue;   // slots with a pending shadow ray: shade block b owns entries [256 b, 256 b + shadow_count[b]) -- no atomics
+    uint32_t* shadow_count;   // entries each shade block wrote this iteration
     uint32_t P;         // slots
-    uint32_t shard_cap; // capacity of one shadow-queue shard = ceil(blocks / WF_SHARDS) * MCPT_BLOCK
 };
 
 #define WF_SHARDS 8          // shadow-queue shards (block b appends to shard b % 8: 8x less contention on the cursor)
 #define WF_COUNTER_REPLICAS 1024
 #define WF_ITEM_SHARDS 64
-#define WF_LDS_MATS 64        // material tables up to this size are staged in LDS by the shade kernel (256 threads x 16 B = 64 x 64 B)
+#define WF_LDS_MATS 32        // material / light tables up to these sizes are staged in LDS by the shade kernel
+#define WF_LDS_LIGHTS 16
 
 struct IterCtl {        // indexed [iteration & 3]; shade(it) zeroes entry (it+1)&3 for the next iteration
     uint32_t trace_head[4];
     uint32_t any_active[4];              // set (plain store) by any wave that still owns a live slot
-    uint32_t n_shadow[4][WF_SHARDS];     // entries appended to each shard of the shadow queue
-    uint32_t pad[8];
+    uint32_t pad[8 + 4 * WF_SHARDS];
     struct { uint32_t v; uint32_t pad[15]; } item_cursor[WF_ITEM_SHARDS];   // work-item cursors, one 64-B line each
 };
 

@@ -64,9 +64,22 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
                                                               float4* __restrict__ accum, DevCounters* gcnt) {
     const uint32_t slot = blockIdx.x * MCPT_BLOCK + threadIdx.x;           // pool.P is a multiple of MCPT_BLOCK
     const uint32_t lane = threadIdx.x & 63;
-    if (slot < WF_SHARDS) { const uint32_t n = (it + 1) & 3; ctl->n_shadow[n][slot] = 0; if (slot == 0) { ctl->trace_head[n] = 0; ctl->any_active[n] = 0; } }
+    if (slot == 0) { const uint32_t n = (it + 1) & 3; ctl->trace_head[n] = 0; ctl->any_active[n] = 0; }
     __shared__ uint32_t s_wave_cnt[MCPT_BLOCK / 64];
     __shared__ uint32_t s_base, s_sel;
+    // Small scene tables staged in LDS once per block: every scattered global load costs vector-memory issue time whether its
+    // lanes hit 2 distinct lines or 64, and shade was bound by ~25 of them per wave.  Lights (record + fp64 corners) and
+    // materials are tiny in typical scenes; larger tables fall back to global memory.
+    __shared__ float4 s_mats[WF_LDS_MATS * 4];
+    __shared__ float4 s_lights[WF_LDS_LIGHTS * 4];
+    __shared__ double s_light_pos[WF_LDS_LIGHTS * 9];
+    const bool mats_lds = sc.n_mats <= WF_LDS_MATS, lights_lds = sc.n_lights <= WF_LDS_LIGHTS;
+    if (mats_lds && threadIdx.x < (uint32_t)sc.n_mats * 4) s_mats[threadIdx.x] = reinterpret_cast<const float4*>(sc.mats)[threadIdx.x];
+    if (lights_lds) {
+        if (threadIdx.x < (uint32_t)sc.n_lights * 4) s_lights[threadIdx.x] = reinterpret_cast<const float4*>(sc.lights)[threadIdx.x];
+        if (threadIdx.x < (uint32_t)sc.n_lights * 9) s_light_pos[threadIdx.x] = sc.tri_pos64[9 * (size_t)sc.lights[threadIdx.x / 9].tri + threadIdx.x % 9];
+    }
+    __syncthreads();
 
     const float4 bt = ld_s(&pool.beta[slot]);
     const uint32_t st = __float_as_uint(bt.w);
@@ -80,8 +93,8 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     uint4 id = ld_s(&pool.ids[slot]);                                              // pixel, sample, s_next, s_end
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f); bool sm_loaded = false;    // item accumulator: fetched only when a path ends
     // one batch of requests for everything an ALIVE slot needs about its traced ray (nearly every slot is ALIVE in steady state)
-    float4 h = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f), ro4 = h, rd4 = h; double4 og = make_double4(0, 0, 0, 0);
-    if (state == SLOT_ALIVE) { h = ld_s(&pool.hit[slot]); ro4 = ld_s(&pool.ray_o[slot]); rd4 = ld_s(&pool.ray_d[slot]); og = ld_s(&pool.org64[slot]); }
+    // (requested unconditionally so they go out in the same batch as beta / L / ids: one memory round trip for all slot state)
+    const float4 h = ld_s(&pool.hit[slot]), ro4 = ld_s(&pool.ray_o[slot]), rd4 = ld_s(&pool.ray_d[slot]); const double4 og = ld_s(&pool.org64[slot]);
     const float nl = (float)sc.n_lights;
     const bool correct_t2 = (p.flags & MCPT_FLAG_CORRECT_SHADOW_T2) != 0;
 
@@ -104,16 +117,48 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         const int tri = __float_as_int(h.x);
 #endif
         if (tri < 0) { terminated = true; break; }                                             // Render.cpp:118-119,144-145
+#if defined(MCPT_ABLATE_X) || defined(MCPT_ABLATE_Y)   // timing diagnostics (garbage image): X = no gathers / no math, Y = gathers only
+        {
+            f3 nn = mk3(0.f, 1.f, 0.f); f3 pp = xyz(ro4) + xyz(rd4) * h.w;
+#ifdef MCPT_ABLATE_Y
+            { const HitShade hs_ = load_hit_shade(sc, tri, h.y, h.z, xyz(rd4)); nn = hs_.n; const d3 q_ = hit_point64_plane(sc, tri, mkd(og.x, og.y, og.z), xyz(rd4)); pp = to_f3(q_); }
+#endif
+            if (bounce >= 3) { terminated = true; break; }
+            const Rng4 r_ = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
+            nee = mk3(0.01f, 0.01f, 0.01f); sh_dir = normalize(mk3(r_.v[0] - 0.5f, 0.9f, r_.v[1] - 0.5f)); sh_t2 = 0.3f; sh_skip = -1; emit_shadow = r_.v[2] < 0.43f;
+#ifdef MCPT_ABLATE_X2
+            emit_shadow = false;
+#endif
+            no = pp; no64 = to_d3(pp); nd = normalize(nn + mk3(r_.v[1] - 0.5f, r_.v[2] - 0.5f, r_.v[3] - 0.5f)); bounce++; emit_extend = true; c_cont = true;
+            break;
+        }
+#endif
         float hu, hv;
         const f3 prev_p = xyz(ro4), d = xyz(rd4);
         // second batch: the light record + its fp64 corners are requested NOW (they depend only on the RNG key), together with
         // the hit triangle's fp64 corners and shading record below -- one memory round trip instead of two
         const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
-        const LightData ld = light_fetch(sc, ra.v[0]);
-        const d3 p64 = hit_point64(sc, tri, mkd(og.x, og.y, og.z), d, hu, hv);               // og = fp64 origin of the traced ray
+        hu = h.y; hv = h.z;                                                                      // fp32 barycentrics of the traversal
+        const d3 p64 = hit_point64_plane(sc, tri, mkd(og.x, og.y, og.z), d);                    // og = fp64 origin of the traced ray
         const f3 p32 = to_f3(p64);
+        // Light sample first (Render.cpp:124 draws it before anything else uses it): its fp64 temporaries are dead before the
+        // BSDF state below comes alive -- keeps the kernel under the next VGPR occupancy step.
+        LightSample ls;
+        {
+            LightData ld;
+            if (lights_lds) {
+                const int cnt = sc.n_lights;
+                int li = (int)(ra.v[0] * (float)cnt); li = li < cnt - 1 ? li : cnt - 1;              // Render.cpp:204-205
+                ld.a = s_lights[4 * li]; ld.b = s_lights[4 * li + 1]; ld.c = s_lights[4 * li + 2]; ld.e = s_lights[4 * li + 3];
+                const double* LP = s_light_pos + 9 * li;
+                ld.v0 = mkd(LP[0], LP[1], LP[2]); ld.v1 = mkd(LP[3], LP[4], LP[5]); ld.v2 = mkd(LP[6], LP[7], LP[8]);
+            } else ld = light_fetch(sc, ra.v[0]);
+            ls = sample_light(ld, p64, ra.v[1], ra.v[2], true);
+        }
         const HitShade hs = load_hit_shade(sc, tri, hu, hv, d);
-        const DevMaterial& mat = sc.mats[hs.mat];
+        DevMaterial mat;
+        if (mats_lds) { float4* m4 = reinterpret_cast<float4*>(&mat); m4[0] = s_mats[4 * hs.mat]; m4[1] = s_mats[4 * hs.mat + 1]; m4[2] = s_mats[4 * hs.mat + 2]; m4[3] = s_mats[4 * hs.mat + 3]; }
+        else mat = sc.mats[hs.mat];
         c_shaded = true;
         if (bounce > 0) {
             if ((mat.flags & MAT_EMISSIVE) && hs.front) {                                       // Render.cpp:146-162
@@ -141,7 +186,6 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         const f3 kd = tex_color(sc, mat, hs.tu, hs.tv, c_texel);
         const Bsdf bsdf = make_bsdf(mat, kd, hs.n, -d);
         const Rng4 rb = rng_block(id.x, id.y, 2u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
-        const LightSample ls = sample_light(ld, p64, ra.v[1], ra.v[2], true);                  // Render.cpp:124
         if (ls.pdf != 0.f) {
             c_self_t = true; c_self_h = ls.self_hit;
             if (correct_t2 || !ls.self_hit) {
@@ -249,20 +293,18 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     if (sum_dirty && sm_loaded) st_s(&pool.sum[slot], sm);
     if (id_dirty) st_s(&pool.ids[slot], id);
 
-    // ---- shadow queue append: ranks inside the block through LDS, ONE atomic per block on the block's shard cursor
-    const uint32_t cur = it & 3, wv = threadIdx.x >> 6, shard = blockIdx.x & (WF_SHARDS - 1);
+    // ---- shadow queue append, atomic-free: ranks inside the block through LDS; the block owns queue entries [256 b, 256 b + n) and
+    //      publishes n with a plain store.  (A returning atomic per block on a shared cursor -- even sharded 8 ways -- held every
+    //      block's four waves at the barrier for its round trip: 0.58 vs 0.24 ms per launch.)
+    const uint32_t cur = it & 3, wv = threadIdx.x >> 6;
     const uint64_t ms = __ballot(emit_shadow);
     if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(ms);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
-        s_base = tot ? atomicAdd(&ctl->n_shadow[cur][shard], tot) : 0u;
-    }
-    __syncthreads();
+    if (threadIdx.x == 0) st_s(&pool.shadow_count[blockIdx.x], s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3]);
     if (emit_shadow) {
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
-        st_s(&pool.shadow_queue[shard * pool.shard_cap + s_base + before + lane_rank(ms)], slot);
+        st_s(&pool.shadow_queue[blockIdx.x * MCPT_BLOCK + before + lane_rank(ms)], slot);
     }
     // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
     const uint64_t ma = __ballot(state != SLOT_DEAD);
@@ -290,6 +332,9 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
 // that lanes reading different nodes spread over the banks) + a 16-entry per-lane stack (64 KB); deeper stack entries (rare)
 // spill to a global overflow area.  One block per CU: 16 waves / CU.
 #define WF_TRACE_BLOCK 1024
+#ifndef WF_CHUNK_BATCH
+#define WF_CHUNK_BATCH 4
+#endif
 #define WF_LDS_STACK 16
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
@@ -313,20 +358,22 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = pool.P;
-    uint32_t sh_end[WF_SHARDS];            // exclusive prefix ends of the shadow shards in the ray list (uniform -> SGPRs)
-    {
-        uint32_t acc = P;
-        for (int q = 0; q < WF_SHARDS; q++) { acc += ctl->n_shadow[it & 3][q]; sh_end[q] = acc; }
-    }
-    const uint32_t total = sh_end[WF_SHARDS - 1];
+    // Ray list = 2 * P / 256 chunks: chunk c < P/256 holds the extend rays of slots [256 c, 256 c + 256); chunk P/256 + b holds the
+    // shadow rays shade block b queued (shadow_count[b] of them).  A wave owns one chunk at a time: the first statically (no atomic),
+    // later ones from `head`.
+    const uint32_t n_ext_chunks = P / MCPT_BLOCK, n_chunks = 2 * n_ext_chunks;
     uint32_t* head = &ctl->trace_head[it & 3];
-
-    // wave-private slice of the ray list: the first chunk is assigned statically (no atomic), later ones come from `head`
     const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
-    uint32_t w_next = (blockIdx.x * (WF_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) * tune.chunk;
-    uint32_t w_end = min(w_next + tune.chunk, total);
-    bool exhausted = false;
-    if (w_next >= total) { w_next = w_end = 0; }
+    uint32_t w_next = 0, w_end = 0, q_base = 0;      // current chunk: item range [w_next, w_end); shadow chunks: queue offset q_base
+    bool chunk_shadow = false, exhausted = false;
+    auto take_chunk = [&](uint32_t c) {
+        if (c >= n_chunks) { exhausted = true; w_next = w_end = 0; return; }
+        if (c < n_ext_chunks) { chunk_shadow = false; w_next = c * MCPT_BLOCK; w_end = w_next + MCPT_BLOCK; }
+        else { chunk_shadow = true; const uint32_t b = c - n_ext_chunks; q_base = b * MCPT_BLOCK; w_next = 0; w_end = wave_first(ld_s(&pool.shadow_count[b])); }
+    };
+    // chunks are reserved WF_CHUNK_BATCH at a time: one atomic on `head` per ~1-2 k rays per wave
+    uint32_t c_next = (blockIdx.x * (WF_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) * WF_CHUNK_BATCH, c_end = c_next + WF_CHUNK_BATCH;
+    take_chunk(c_next++);
 
     bool have = false, any = false, blocked = false;
     uint32_t slot = 0; int skip = -1;
@@ -357,43 +404,48 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                 have = false;
             }
             if (!exhausted) {
+                // hand every idle lane the next ray of the list; a refill may cross chunk boundaries (shadow chunks are short)
                 const uint64_t m_idle = __ballot(!have);
-                if (w_next == w_end) {                                   // reserve the next chunk of the list (uniform branch)
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(head, tune.chunk);
-                    base = wave_first(base) + n_waves * tune.chunk;
-                    if (base >= total) exhausted = true;
-                    else { w_next = base; w_end = min(base + tune.chunk, total); }
-                }
-                if (!exhausted) {
-                    const uint32_t w = w_next + lane_rank(m_idle);
-                    if (!have && w < w_end) {
-                        bool valid;
-                        if (w < P) {                                     // extend ray of slot w
-                            slot = w;
-                            const float4 rd = ld_s(&pool.ray_d[w]);
-                            valid = rd.w != 0.f;
-                            const float4 ro = ld_s(&pool.ray_o[w]);
-                            o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; skip = -1;
-                        } else {                                         // shadow ray of a queued slot
-                            uint32_t q = 0, lo = P;
-                            for (int k = 0; k < WF_SHARDS - 1; k++) if (w >= sh_end[k]) { q = k + 1; lo = sh_end[k]; }
-                            slot = ld_s(&pool.shadow_queue[q * pool.shard_cap + (w - lo)]);
-                            const float4 ro = ld_s(&pool.ray_o[slot]), sd = ld_s(&pool.sh_d[slot]);
-                            o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; skip = __float_as_int(ro.w); valid = true;
+                const uint32_t rank = lane_rank(m_idle);
+                uint32_t remaining = (uint32_t)__popcll(m_idle), assigned = 0;
+                bool got = false, my_shadow = false; uint32_t my_w = 0, my_q = 0;
+                for (int pass = 0; pass < 4 && remaining > 0; pass++) {
+                    if (w_next == w_end) {                               // next chunk (uniform branch)
+                        if (c_next == c_end) {
+                            uint32_t c = 0;
+                            if (lane == 0) c = atomicAdd(head, (uint32_t)WF_CHUNK_BATCH);
+                            c_next = wave_first(c) + n_waves * WF_CHUNK_BATCH; c_end = c_next + WF_CHUNK_BATCH;
                         }
-                        if (valid) {
-                            const float tiny = 1e-30f;
-                            idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
-                            idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
-                            idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
-                            oodx = o.x * idx; oody = o.y * idy; oodz = o.z * idz;
-                            stk[0] = MCPT_NODE_SENTINEL; sp = 1; node = 0;
-                            htri = -1; ht = 0.f; hu = 0.f; hv = 0.f; blocked = false;
-                            have = true;
-                        }
+                        take_chunk(c_next++);
+                        if (exhausted) break;
                     }
-                    w_next = min(w_next + (uint32_t)__popcll(m_idle), w_end);
+                    const uint32_t take = min(w_end - w_next, remaining);
+                    if (!have && !got && rank >= assigned && rank < assigned + take) { got = true; my_w = w_next + (rank - assigned); my_shadow = chunk_shadow; my_q = q_base; }
+                    w_next += take; assigned += take; remaining -= take;
+                }
+                if (got) {
+                    bool valid;
+                    if (!my_shadow) {                                    // extend ray of slot my_w
+                        slot = my_w;
+                        const float4 rd = ld_s(&pool.ray_d[my_w]);
+                        valid = rd.w != 0.f;
+                        const float4 ro = ld_s(&pool.ray_o[my_w]);
+                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; skip = -1;
+                    } else {                                             // shadow ray of a queued slot
+                        slot = ld_s(&pool.shadow_queue[my_q + my_w]);
+                        const float4 ro = ld_s(&pool.ray_o[slot]), sd = ld_s(&pool.sh_d[slot]);
+                        o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; skip = __float_as_int(ro.w); valid = true;
+                    }
+                    if (valid) {
+                        const float tiny = 1e-30f;
+                        idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+                        idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+                        idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+                        oodx = o.x * idx; oody = o.y * idy; oodz = o.z * idz;
+                        stk[0] = MCPT_NODE_SENTINEL; sp = 1; node = 0;
+                        htri = -1; ht = 0.f; hu = 0.f; hv = 0.f; blocked = false;
+                        have = true;
+                    }
                 }
             }
             if (exhausted && __ballot(have) == 0) break;
