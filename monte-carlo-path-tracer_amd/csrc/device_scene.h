@@ -27,7 +27,9 @@
 #define MCPT_STACK_DEPTH 32        // LDS traversal stack entries per lane (BVH builder guarantees depth <= this)
 #endif
 #define MCPT_BLOCK 256             // threads per workgroup = 4 waves of 64
-#define MCPT_TOP_NODES 1024        // nodes numbered breadth-first by the builder; the trace kernel serves them from LDS
+#ifndef MCPT_TOP_NODES
+#define MCPT_TOP_NODES 256         // nodes numbered breadth-first by the builder; the trace kernel serves them from LDS
+#endif
 #define MCPT_NODE_SENTINEL ((int)0x80000000)
 
 struct DevMaterial {               // Material (model.h:32-40) + its Texture header (model.h:21-30)

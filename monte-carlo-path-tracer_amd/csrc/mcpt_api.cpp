@@ -194,7 +194,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         const uint64_t pixels = uint64_t(c->width) * c->height;
         uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 22);
         if (P < 2048) P = 2048;
-        c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 24);
+        c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
         c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.chunk = env_u32("MCPT_WF_CHUNK", 256);
         c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0) != 0;
         (void)pixels;

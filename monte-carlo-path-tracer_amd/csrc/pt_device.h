@@ -55,9 +55,6 @@ DEV double rsq64(double x) { double r = __builtin_amdgcn_rsq(x); r = fma(fma(-0.
 // of (pixel, sample, block, seed).  Block layout per path: DESIGN.md §RNG (0 = camera; 1+2b / 2+2b = bounce b).
 struct Rng4 { float v[4]; };
 DEV Rng4 rng_block(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed_lo, uint32_t seed_hi) {
-#ifdef MCPT_ABLATE_RNG
-    { Rng4 r; const float f = (float)((pixel * 2654435761u + sample * 40503u + block * 97u) >> 8) * (1.0f / 16777216.0f); r.v[0] = f; r.v[1] = 1.f - f; r.v[2] = 0.5f * f; r.v[3] = 0.25f + 0.5f * f; return r; }
-#endif
     uint32_t x = pixel, y = sample, z = block ^ (seed_hi * 0x9E3779B9u), w = seed_lo;
     x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u; z = z * 1664525u + 1013904223u; w = w * 1664525u + 1013904223u;
     x += y * w; y += z * x; z += x * y; w += y * z;
@@ -188,10 +185,6 @@ DEV HitShade load_hit_shade(const DevScene& sc, int tri, float u, float v, f3 d)
 // identical to the reference's -- they decide the light self-occlusion of SURVEY A-9 (with fp32 barycentrics the point is
 // exactly fp32-representable on axis-aligned walls and the image comes out 1.2 % darker than the reference).
 DEV d3 hit_point64(const DevScene& sc, int tri, d3 o64, f3 dir, float& u_out, float& v_out) {
-#ifdef MCPT_ABLATE_HIT64
-    { const float4* T = sc.tri_isect + 3 * (size_t)tri; const float4 a = T[0], b = T[1], c = T[2]; u_out = 0.3f; v_out = 0.3f;
-      return mkd(a.x + 0.3f * (b.x + c.x), a.y + 0.3f * (b.y + c.y), a.z + 0.3f * (b.z + c.z)); }
-#endif
     const double* P = sc.tri_pos64 + 9 * (size_t)tri;
     const d3 v0 = ld_d3(P), v1 = ld_d3(P + 3), v2 = ld_d3(P + 6);
     const d3 e1 = v1 - v0, e2 = v2 - v0, dd = to_d3(dir);
@@ -280,9 +273,6 @@ DEV float phong_pdf(const Bsdf& b, f3 wi) {
 DEV float diffuse_pdf(const Bsdf& b, f3 wi) { return (wi.z < 0.f || b.m_wo.z < 0.f) ? 0.f : (wi.z * PT_INV_PI); }   // BSDF.cpp:28-31
 // BSDF::Fx (BSDF.cpp:112-121) and BSDF::Pdf (:153-163) for a world direction; Diffuse::Fx has no hemisphere test (A-22)
 DEV void bsdf_eval(const Bsdf& b, f3 dir_world, f3& fx, float& pdf) {
-#ifdef MCPT_ABLATE_BSDF_EVAL
-    fx = b.kd; pdf = 0.3f; return;
-#endif
     const f3 wo = to_local(b, dir_world);
     fx = b.kd * PT_INV_PI;
     pdf = diffuse_pdf(b, wo) * b.w_diff;
@@ -293,9 +283,6 @@ struct Scatter { f3 wo, f; float pdf; bool mirror; };
 // specular_reflection::Sample (:78-85).  xi_lobe picks the lobe through the weight prefix sums (lower_bound).
 DEV Scatter bsdf_sample(const Bsdf& b, float xi_lobe, float xi1, float xi2) {
     Scatter s; s.wo = mk3(0.f, 0.f, 0.f); s.f = mk3(0.f, 0.f, 0.f); s.pdf = 0.f; s.mirror = false;
-#ifdef MCPT_ABLATE_BSDF_SAMPLE
-    s.wo = normalize(b.w + mk3(xi1 - 0.5f, xi2 - 0.5f, xi_lobe - 0.5f)); s.f = b.kd; s.pdf = 1.f; return s;
-#endif
     const bool two = b.kind != BSDF_DIFFUSE;
     const float total = two ? (b.w_spec + b.w_diff) : b.w_diff;
     const bool pick_spec = two && (b.w_spec >= xi_lobe * total);
@@ -398,11 +385,7 @@ DEV LightSample sample_light(const LightData& ld, d3 p64, float xi_u, float xi_v
     const d3 h = cross(dd, e2);
     const double det = dot(e1, h);
     bool self = false;
-#ifdef MCPT_ABLATE_SELFHIT
-    if (false) {
-#else
     if (!(fabs(det) < 1e-6)) {
-#endif
         const double inv = rcp64(det);
         const d3 s = p64 - v0;
         const double uu = inv * dot(s, h);

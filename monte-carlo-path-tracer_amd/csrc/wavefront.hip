@@ -117,22 +117,6 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         const int tri = __float_as_int(h.x);
 #endif
         if (tri < 0) { terminated = true; break; }                                             // Render.cpp:118-119,144-145
-#if defined(MCPT_ABLATE_X) || defined(MCPT_ABLATE_Y)   // timing diagnostics (garbage image): X = no gathers / no math, Y = gathers only
-        {
-            f3 nn = mk3(0.f, 1.f, 0.f); f3 pp = xyz(ro4) + xyz(rd4) * h.w;
-#ifdef MCPT_ABLATE_Y
-            { const HitShade hs_ = load_hit_shade(sc, tri, h.y, h.z, xyz(rd4)); nn = hs_.n; const d3 q_ = hit_point64_plane(sc, tri, mkd(og.x, og.y, og.z), xyz(rd4)); pp = to_f3(q_); }
-#endif
-            if (bounce >= 3) { terminated = true; break; }
-            const Rng4 r_ = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
-            nee = mk3(0.01f, 0.01f, 0.01f); sh_dir = normalize(mk3(r_.v[0] - 0.5f, 0.9f, r_.v[1] - 0.5f)); sh_t2 = 0.3f; sh_skip = -1; emit_shadow = r_.v[2] < 0.43f;
-#ifdef MCPT_ABLATE_X2
-            emit_shadow = false;
-#endif
-            no = pp; no64 = to_d3(pp); nd = normalize(nn + mk3(r_.v[1] - 0.5f, r_.v[2] - 0.5f, r_.v[3] - 0.5f)); bounce++; emit_extend = true; c_cont = true;
-            break;
-        }
-#endif
         float hu, hv;
         const f3 prev_p = xyz(ro4), d = xyz(rd4);
         // second batch: the light record + its fp64 corners are requested NOW (they depend only on the RNG key), together with
@@ -335,7 +319,9 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
 #ifndef WF_CHUNK_BATCH
 #define WF_CHUNK_BATCH 4
 #endif
-#define WF_LDS_STACK 16
+#ifndef WF_LDS_STACK
+#define WF_LDS_STACK 12
+#endif
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
                                                                   int* __restrict__ stack_overflow) {
