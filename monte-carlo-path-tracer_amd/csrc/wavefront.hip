@@ -504,11 +504,24 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                 WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2) WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
 #undef WF_CSWAP
                 const float inf = __builtin_inff();
-                if (key3 < inf) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd3; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd3; sp++; }
-                if (key2 < inf) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd2; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd2; sp++; }
-                if (key1 < inf) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd1; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd1; sp++; }
-                if (key0 < inf) node = cd0;
-                else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
+                const int h1 = key1 < inf, h2 = key2 < inf, h3 = key3 < inf;      // sorted: hits are a prefix
+                if (sp + 3 <= WF_LDS_STACK) {
+                    // common case, branch-free: store all three candidates, advance the stack pointer only past real hits (a slot
+                    // written without the bump is simply overwritten later); the pop reads the slot below the new top
+                    stk[sp * WF_TRACE_BLOCK] = cd3; sp += h3;
+                    stk[sp * WF_TRACE_BLOCK] = cd2; sp += h2;
+                    stk[sp * WF_TRACE_BLOCK] = cd1; sp += h1;
+                    const int below = stk[(sp - 1) * WF_TRACE_BLOCK];
+                    const bool hit0 = key0 < inf;
+                    node = hit0 ? cd0 : below;
+                    sp -= hit0 ? 0 : 1;
+                } else {                                                   // rare: near the LDS limit -> entries may go to the overflow area
+                    if (h3) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd3; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd3; sp++; }
+                    if (h2) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd2; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd2; sp++; }
+                    if (h1) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd1; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd1; sp++; }
+                    if (key0 < inf) node = cd0;
+                    else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
+                }
             }
         } while (__popcll(__ballot(have && node >= 0)) >= (int)tune.inner_keep);
     }

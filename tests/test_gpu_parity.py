@@ -311,3 +311,27 @@ def test_cpp_cli_end_to_end(pkg, tmp_path):
     r = pkg.Renderer(s, max_depth=4, flags=pkg.FLAG_DETERMINISTIC); r.render(8, seed=5); want = r.tonemap(flip_y=True); r.close()
     assert png.shape == want.shape
     assert (np.abs(png.astype(int) - want.astype(int)) <= 1).mean() > 0.995   # host powf vs device powf at a rounding edge
+
+
+@pytest.mark.parametrize("name,kw,res,depth", [("veach-mis", {}, (1280, 720), 0), ("bathroom2", {"detail": 160}, (1920, 1080), 8)])
+def test_full_size_properties_other_configs(pkg, name, kw, res, depth):
+    """configs[2] geometry (S-veach 1280x720, 3840 light triangles) and configs[3] geometry (S-bath 1920x1080, 0.59 M triangles,
+    four image textures, mirror) at reduced spp: count plane, finiteness, additivity of sample ranges, ray accounting,
+    BVH invariants reported by the library."""
+    scene = pkg.scenes.SCENES[name](res[0], res[1], **kw)
+    r = pkg.Renderer(scene, max_depth=depth)
+    info = r.info()
+    assert info.n_tris == scene.n_faces and info.bvh_depth <= 30 and info.max_leaf <= 4
+    r.render(4, seed=3, first_sample=0); r.render(4, seed=3, first_sample=4); ab = r.read_accum()
+    r.clear(); r.reset_counters(); r.render(8, seed=3); whole = r.read_accum(); c = r.counters(); r.close()
+    assert np.all(whole[..., 3] == 8) and np.all(ab[..., 3] == 8) and np.isfinite(whole).all()
+    assert np.allclose(ab, whole, rtol=1e-4, atol=1e-4)
+    assert c.paths == res[0] * res[1] * 8 == c.rays_primary
+    assert 2.0 < c.rays / c.paths < 12.0 and c.self_shadow_hits <= c.self_shadow_tests
+    m = (whole[..., :3] / 8).mean()
+    assert 0.01 < m < 10.0
+
+
+def test_smoke_entry_point():
+    import __graft_entry__ as ge
+    ge.smoke()
