@@ -137,6 +137,8 @@ mcpt_status mcpt_check_scene(const mcpt_scene_desc* scene, mcpt_scene_info* out_
     HostScene hs; std::string err;
     mcpt_status st = build_host_scene(scene, hs, err);
     if (st != MCPT_OK) return fail(st, err);
+    const std::string bad = validate_bvh4(hs);
+    if (!bad.empty()) return fail(MCPT_ERR_UNSUPPORTED, "internal: 4-wide BVH failed its self-check: " + bad);
     if (out_info) {
         std::memset(out_info, 0, sizeof *out_info);
         out_info->n_tris = uint32_t(hs.tri_face.size()); out_info->n_lights = uint32_t(hs.lights.size()); out_info->n_nodes = uint32_t(hs.nodes.size() / 4);
@@ -191,13 +193,11 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         c->n_cus = prop.multiProcessorCount;
         const char* pipe = std::getenv("MCPT_PIPELINE");
         c->use_wavefront = !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS;
-        const uint64_t pixels = uint64_t(c->width) * c->height;
         uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 22);
         if (P < 2048) P = 2048;
         c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
         c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.chunk = env_u32("MCPT_WF_CHUNK", 256);
         c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0) != 0;
-        (void)pixels;
         if (c->use_wavefront) {
             uint32_t n_lanes = env_u32("MCPT_WF_LANES", 2);
             if (n_lanes < 1) n_lanes = 1;

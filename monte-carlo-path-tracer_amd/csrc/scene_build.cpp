@@ -235,6 +235,51 @@ void build_bvh4(HostScene& out) {
 
 }  // namespace
 
+// Self-check used by mcpt_check_scene: walk the 4-wide tree exactly as the kernel dequantises it (fp32: origin + q * 2^e) and verify
+// that every leaf triangle's fp32 test data (v0, v0+e1, v0+e2) lies inside every box on its root path, that every triangle is
+// referenced exactly once, and that child links are in range.  Returns an empty string when the tree is sound.
+std::string validate_bvh4(const HostScene& hs) {
+    const size_t n4 = hs.nodes4.size() / 4, nt = hs.tri_face.size();
+    if (n4 == 0) return "empty nodes4";
+    std::vector<uint8_t> seen(nt, 0);
+    struct Item { int node; float lo[3], hi[3]; };
+    std::vector<Item> stack;
+    Item root; root.node = 0; for (int a = 0; a < 3; a++) { root.lo[a] = -INFINITY; root.hi[a] = INFINITY; }
+    stack.push_back(root);
+    size_t visited = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        if (it.node < 0 || size_t(it.node) >= n4) return "child link out of range";
+        if (++visited > n4) return "cycle in nodes4";
+        const f4h* r = &hs.nodes4[4 * size_t(it.node)];
+        const uint32_t meta = as_u32(r[0].w);
+        const float sc[3] = {from_u32((meta & 0xffu) << 23), from_u32(((meta >> 8) & 0xffu) << 23), from_u32(((meta >> 16) & 0xffu) << 23)};
+        const float org[3] = {r[0].x, r[0].y, r[0].z};
+        const uint32_t q[6] = {as_u32(r[1].x), as_u32(r[1].y), as_u32(r[1].z), as_u32(r[1].w), as_u32(r[2].x), as_u32(r[2].y)};
+        const int codes[4] = {int(as_u32(r[3].x)), int(as_u32(r[3].y)), int(as_u32(r[3].z)), int(as_u32(r[3].w))};
+        for (int k = 0; k < 4; k++) {
+            if (!((meta >> (24 + k)) & 1u)) continue;
+            Item ch; ch.node = codes[k];
+            for (int a = 0; a < 3; a++) {
+                const float lo = org[a] + float((q[a] >> (8 * k)) & 0xffu) * sc[a], hi = org[a] + float((q[3 + a] >> (8 * k)) & 0xffu) * sc[a];
+                ch.lo[a] = std::max(it.lo[a], lo); ch.hi[a] = std::min(it.hi[a], hi);     // a point must be inside EVERY box on the path
+            }
+            if (codes[k] >= 0) { stack.push_back(ch); continue; }
+            const uint32_t leaf = uint32_t(~codes[k]), first = leaf >> 3, cnt = leaf & 7u;
+            if (size_t(first) + cnt > nt) return "leaf range out of bounds";
+            for (uint32_t t = first; t < first + cnt; t++) {
+                if (seen[t]++) return "triangle referenced twice";
+                const f4h v0 = hs.tri_isect[3 * size_t(t)], e1 = hs.tri_isect[3 * size_t(t) + 1], e2 = hs.tri_isect[3 * size_t(t) + 2];
+                const float P[3][3] = {{v0.x, v0.y, v0.z}, {v0.x + e1.x, v0.y + e1.y, v0.z + e1.z}, {v0.x + e2.x, v0.y + e2.y, v0.z + e2.z}};
+                for (int c = 0; c < 3; c++) for (int a = 0; a < 3; a++)
+                    if (!(P[c][a] >= ch.lo[a] && P[c][a] <= ch.hi[a])) return "triangle " + std::to_string(t) + " sticks out of a quantised box on its path";
+            }
+        }
+    }
+    for (size_t t = 0; t < nt; t++) if (!seen[t]) return "triangle " + std::to_string(t) + " not reachable";
+    return "";
+}
+
 mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err) {
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
     if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }

@@ -28,3 +28,6 @@ struct HostScene {
 // Validates the description (indices in range, sizes non-zero), flattens faces, collects lights, builds the BVH.
 // Returns MCPT_OK or an error code with `err` filled.
 mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err);
+
+// Host-side soundness check of the quantised 4-wide tree (empty string = sound); run by mcpt_check_scene.
+std::string validate_bvh4(const HostScene& hs);

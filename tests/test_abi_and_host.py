@@ -104,6 +104,29 @@ def test_reference_undefined_behaviour_becomes_error_codes(pkg):
     assert st == 1
 
 
+def test_quantised_bvh4_is_conservative_on_awkward_geometry(pkg):
+    """mcpt_check_scene walks the 4-wide tree as the kernel dequantises it and fails if any triangle sticks out of a box on its path.
+    Feed it geometry that stresses the 8-bit frames: huge coordinate offsets, tiny and huge triangles side by side, flat boxes."""
+    rng = np.random.RandomState(11)
+    base = pkg.scenes.open_box(8, 8)
+    n = 3000
+    centres = rng.uniform(-1, 1, (n, 3)) * np.array([1e3, 1.0, 1e-3]) + np.array([5e4, -3.0, 0.25])
+    size = 10.0 ** rng.uniform(-5, 1, (n, 1, 1))
+    tri = centres[:, None, :] + size * rng.normal(size=(n, 3, 3))
+    tri[::7, :, 1] = tri[::7, :1, 1]                                    # axis-aligned flat triangles
+    v = np.concatenate([base.vertex, tri.reshape(-1, 3)])
+    nrm = np.concatenate([base.normal, np.tile([[0.0, 1.0, 0.0]], (3 * n, 1))])
+    tc = np.concatenate([base.texcoord, np.zeros((3 * n, 2))])
+    off = base.vertex.shape[0]
+    f = np.zeros((n, 3, 4), np.int32)
+    for k in range(3):
+        f[:, k, 0] = f[:, k, 1] = f[:, k, 2] = off + 3 * np.arange(n) + k
+    face = np.concatenate([base.face, f])
+    st, info, msg = pkg.check_scene(pkg.scenes.SceneData("stress", v, nrm, tc, face, base.materials, base.camera))
+    assert st == 0, msg
+    assert info.n_tris == base.n_faces + n and info.bvh_depth <= 30
+
+
 def test_degenerate_geometry_builds(pkg):
     """All centroids equal (SAH cannot split) and a single-leaf scene: the builder must still terminate with a valid tree."""
     s = pkg.scenes.open_box(8, 8)
