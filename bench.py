@@ -47,7 +47,12 @@ def cpu_baseline(pkg, scene, rays_per_path_ref, budget_s=20.0):
         ref = orc.Reference(depth_variant=True)
         tmp = tempfile.mkdtemp(prefix="mcpt_bench_")
         obj = scene.write(tmp)
-        ref.load(obj)
+        sys.stdout.flush()
+        saved = os.dup(1); devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 1)   # the reference prints "[Model] <path>" (model.cpp:46)
+        try:
+            ref.load(obj)
+        finally:
+            os.dup2(saved, 1); os.close(saved); os.close(devnull)
         ref.set_max_bounces(DEPTH)
         ref.stream_mode()
         t1 = ref.render(1)                                   # one frame = one spp for all 640 000 pixels
