@@ -335,3 +335,41 @@ def test_full_size_properties_other_configs(pkg, name, kw, res, depth):
 def test_smoke_entry_point():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_many_materials_use_the_global_table(pkg, orc):
+    """More than WF_LDS_MATS (32) materials: the shade kernel reads materials from global memory instead of its LDS copy."""
+    base = pkg.scenes.cornell_box_small(40, 40)
+    reps = 9                                                            # 5 materials x 9 = 45 > 32
+    mats = [pkg.scenes.Material("%s_%d" % (m.name, k), m.kd, m.ks, m.ns, m.radiance) for k in range(reps) for m in base.materials]
+    face = base.face.copy()
+    face[:, :, 3] = base.face[:, :, 3] + len(base.materials) * (np.arange(base.n_faces) % reps)[:, None]
+    scene = pkg.scenes.SceneData("many-mats", base.vertex, base.normal, base.texcoord, face, mats, base.camera)
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    r = pkg.Renderer(scene, max_depth=5, flags=flags); r.render(16, seed=4); g = r.read_accum(); r.close()
+    cpu, _, _ = orc.Oracle(scene, max_depth=5, flags=flags).render(16, seed=4)
+    assert _frac_beyond(g[..., :3] / 16, cpu[..., :3] / 16) <= 0.01
+    r2 = pkg.Renderer(base, max_depth=5, flags=flags); r2.render(16, seed=4); g2 = r2.read_accum(); r2.close()
+    assert _frac_beyond(g[..., :3] / 16, g2[..., :3] / 16) <= 0.01       # same picture as with the 5-entry (LDS) table
+
+
+@pytest.mark.parametrize("res", [(1, 1), (3, 2), (64, 64)])
+def test_depth_one_and_tiny_images(pkg, orc, res):
+    """max_depth = 1: emission at the first hit + one light sample + the emitter-MIS term of the first BSDF-sampled ray."""
+    scene = pkg.scenes.cornell_box_small(res[0], res[1])
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    r = pkg.Renderer(scene, max_depth=1, flags=flags); r.render(32, seed=9); g = r.read_accum(); c = r.counters(); r.close()
+    cpu, oc, _ = orc.Oracle(scene, max_depth=1, flags=flags).render(32, seed=9)
+    assert g.shape == (res[1], res[0], 4) and np.all(g[..., 3] == 32)
+    assert np.allclose(g[..., :3].sum() / 32, cpu[..., :3].sum() / 32, rtol=5e-3, atol=1e-4)
+    assert c.paths == res[0] * res[1] * 32 and c.rays_continuation <= c.paths     # at most one continuation ray per path
+
+
+def test_frame_by_frame_equals_one_call(pkg):
+    """The reference's usage pattern: `frames` calls of one sample each == one call of `frames` samples."""
+    scene = pkg.scenes.cornell_box_small(32, 32)
+    r = pkg.Renderer(scene, max_depth=6, flags=pkg.FLAG_DETERMINISTIC)
+    for f in range(6):
+        r.render(1, seed=3, first_sample=f)
+    a = r.read_accum(); r.clear(); r.render(6, seed=3); b = r.read_accum(); r.close()
+    assert np.array_equal(a[..., 3], b[..., 3]) and np.allclose(a, b, rtol=2e-5, atol=1e-5)
