@@ -303,9 +303,13 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         if (m_prim) atomicAdd(&g->rays_primary, (unsigned long long)__popcll(m_prim));
         if (m_cont) atomicAdd(&g->rays_continuation, (unsigned long long)__popcll(m_cont));
         if (ms) atomicAdd(&g->rays_shadow, (unsigned long long)__popcll(ms));
+#ifndef WF_SCHED_STATS
         if (m_st) atomicAdd(&g->self_shadow_tests, (unsigned long long)__popcll(m_st));
         if (m_sh) atomicAdd(&g->self_shadow_hits, (unsigned long long)__popcll(m_sh));
+#endif
+#ifndef WF_SCHED_STATS
         if (COUNT) { if (m_shaded) atomicAdd(&g->shaded_hits, (unsigned long long)__popcll(m_shaded)); if (texels) atomicAdd(&g->texel_fetches, texels); }
+#endif
     }
 }
 
@@ -368,6 +372,10 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     int node = MCPT_NODE_SENTINEL, sp = 1;
     int htri = -1; float ht = 0, hu = 0, hv = 0;
     uint32_t n_box = 0, n_tri = 0;
+#ifdef WF_SCHED_STATS
+    uint32_t x_inner = 0, x_leaf = 0, x_refill = 0, l_refill = 0;    // block executions (wave-uniform); n_box / n_tri count lane participations
+#endif
+    const bool greedy = tune.policy == 1;
 
     for (;;) {
         const bool at_inner = have && node >= 0;
@@ -375,8 +383,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
         const int n_inner = __popcll(__ballot(at_inner)), n_leaf = __popcll(__ballot(at_leaf));
         const int n_idle = 64 - n_inner - n_leaf;
 
-        if ((n_inner + n_leaf == 0) || (!exhausted && n_idle >= (int)tune.refill_at)) {
+        const int most = n_inner > n_leaf ? n_inner : n_leaf;
+        if ((n_inner + n_leaf == 0) || (!exhausted && (greedy ? n_idle >= most : n_idle >= (int)tune.refill_at))) {
             // ------------------------------------------------------------------ refill block
+#ifdef WF_SCHED_STATS
+            x_refill++; l_refill += (uint32_t)n_idle;
+#endif
             if (have && node == MCPT_NODE_SENTINEL) {                    // finished: write the result back
                 if (any) {
                     if (!blocked) {                                      // Render.cpp:125-130: unoccluded -> L += NEE term
@@ -438,8 +450,11 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
             continue;
         }
 
-        if (n_leaf >= (int)tune.leaf_at || n_inner == 0) {
+        if ((greedy ? n_leaf >= n_inner : n_leaf >= (int)tune.leaf_at) || n_inner == 0) {
             // ------------------------------------------------------------------ leaf block (all lanes waiting at a leaf)
+#ifdef WF_SCHED_STATS
+            x_leaf++; if (at_leaf) n_tri++;
+#endif
             if (at_leaf) {
                 const uint32_t leaf = (uint32_t)~node;
                 const uint32_t first = leaf >> 3, cnt = leaf & 7u;
@@ -449,7 +464,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     if (ti == skip) continue;
                     const float4* T = sc.tri_isect + 3 * (size_t)ti;
                     const float4 v0 = T[0], e1 = T[1], e2 = T[2];
+#ifndef WF_SCHED_STATS
                     if (COUNT) n_tri++;
+#endif
                     const float hx = d.y * e2.z - e2.y * d.z, hy = d.z * e2.x - e2.z * d.x, hz = d.x * e2.y - e2.x * d.y;
                     const float a = e1.x * hx + e1.y * hy + e1.z * hz;
                     const float sx = o.x - v0.x, sy = o.y - v0.y, sz = o.z - v0.z;
@@ -474,7 +491,11 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
         // = four child boxes, 8-bit offsets in the node's frame.  t = q * (2^e * idir) + (origin * idir - o * idir): two FMAs per
         // plane after one v_cvt_f32_ubyteN.  Hit children are ordered by entry distance (5-comparator network); the nearest is
         // visited next, the others go on the stack far-to-near.  Top levels come from LDS, the rest from memory.
+        int keep = (int)tune.inner_keep;
         do {
+#ifdef WF_SCHED_STATS
+            x_inner++; if (have && node >= 0) n_box++;
+#endif
             if (have && node >= 0) {
                 v4f A, B, C, D;
                 if (node < MCPT_TOP_NODES) { A = top[node]; B = top[MCPT_TOP_NODES + node]; C = top[2 * MCPT_TOP_NODES + node]; D = top[3 * MCPT_TOP_NODES + node]; }
@@ -483,25 +504,37 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                 const float ax = __uint_as_float((meta & 0xffu) << 23) * idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy,
                             az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
                 const float bx = fmaf(A.x, idx, -oodx), by = fmaf(A.y, idy, -oody), bz = fmaf(A.z, idz, -oodz);
+                // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise (and vice versa for the
+                // exit planes): selecting the packed words once per node replaces a min and a max per axis per child
+                const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
                 const uint32_t qlx = __float_as_uint(B.x), qly = __float_as_uint(B.y), qlz = __float_as_uint(B.z), qhx = __float_as_uint(B.w),
                                qhy = __float_as_uint(C.x), qhz = __float_as_uint(C.y);
+                const uint32_t qnx = ngx ? qhx : qlx, qfx = ngx ? qlx : qhx, qny = ngy ? qhy : qly, qfy = ngy ? qly : qhy, qnz = ngz ? qhz : qlz, qfz = ngz ? qlz : qhz;
                 const uint32_t valid = meta >> 24;
                 float key0, key1, key2, key3;
 #define WF_CHILD(K, KEY)                                                                                                             \
                 {                                                                                                                    \
-                    const float t0x = fmaf((float)((qlx >> (8 * K)) & 0xffu), ax, bx), t1x = fmaf((float)((qhx >> (8 * K)) & 0xffu), ax, bx); \
-                    const float t0y = fmaf((float)((qly >> (8 * K)) & 0xffu), ay, by), t1y = fmaf((float)((qhy >> (8 * K)) & 0xffu), ay, by); \
-                    const float t0z = fmaf((float)((qlz >> (8 * K)) & 0xffu), az, bz), t1z = fmaf((float)((qhz >> (8 * K)) & 0xffu), az, bz); \
-                    const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 1e-4f));                  \
-                    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));                   \
+                    const float t0x = fmaf((float)((qnx >> (8 * K)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * K)) & 0xffu), ax, bx); \
+                    const float t0y = fmaf((float)((qny >> (8 * K)) & 0xffu), ay, by), t1y = fmaf((float)((qfy >> (8 * K)) & 0xffu), ay, by); \
+                    const float t0z = fmaf((float)((qnz >> (8 * K)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * K)) & 0xffu), az, bz); \
+                    const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 1e-4f));                                                      \
+                    const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));                                                       \
                     KEY = (((valid >> K) & 1u) && tn <= tf) ? tn : __builtin_inff();                                                 \
                 }
                 WF_CHILD(0, key0) WF_CHILD(1, key1) WF_CHILD(2, key2) WF_CHILD(3, key3)
 #undef WF_CHILD
+#ifndef WF_SCHED_STATS
                 if (COUNT) n_box += (uint32_t)__popc(valid);
+#endif
+#ifdef WF_EXP_VALU   // diagnostic: WF_EXP_VALU extra dependent FMAs per inner step (is the kernel VALU-bound?)
+                { float dm = ax; for (int q = 0; q < WF_EXP_VALU; q++) dm = fmaf(dm, 1.0000001f, ay); if (dm == 12345.678f) key0 = 0.f; }
+#endif
                 int cd0 = __float_as_int(D.x), cd1 = __float_as_int(D.y), cd2 = __float_as_int(D.z), cd3 = __float_as_int(D.w);
 #define WF_CSWAP(KA, CA, KB, CB) { const bool sw = KB < KA; const float tk = sw ? KB : KA; KB = sw ? KA : KB; KA = tk; const int tc = sw ? CB : CA; CB = sw ? CA : CB; CA = tc; }
-                WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2) WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
+                WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2)
+#ifndef WF_PARTIAL_SORT
+                WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
+#endif
 #undef WF_CSWAP
                 const float inf = __builtin_inff();
                 const int h1 = key1 < inf, h2 = key2 < inf, h3 = key3 < inf;      // sorted: hits are a prefix
@@ -523,13 +556,24 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
                 }
             }
-        } while (__popcll(__ballot(have && node >= 0)) >= (int)tune.inner_keep);
+            if (greedy) {                                                  // stay while inner nodes are still what most lanes wait for
+                const int cl = __popcll(__ballot(have && node < 0 && node != MCPT_NODE_SENTINEL)), ci = __popcll(__ballot(have && node >= 0));
+                const int cf = exhausted ? 0 : 64 - cl - ci;
+                keep = (cl > cf ? cl : cf) + 1;
+            }
+        } while (__popcll(__ballot(have && node >= 0)) >= keep);
     }
 
     if (COUNT) {
         unsigned long long b = n_box, t = n_tri;
         for (int off = 32; off > 0; off >>= 1) { b += __shfl_xor(b, off, 64); t += __shfl_xor(t, off, 64); }
-        if (lane == 0) { DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1)); atomicAdd(&g->box_tests, b); atomicAdd(&g->tri_tests, t); }
+        if (lane == 0) {
+            DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1)); atomicAdd(&g->box_tests, b); atomicAdd(&g->tri_tests, t);
+#ifdef WF_SCHED_STATS   // tools/sched_stats.py: the shade-side counters are re-purposed in this diagnostic build
+            atomicAdd(&g->shaded_hits, (unsigned long long)x_inner); atomicAdd(&g->texel_fetches, (unsigned long long)x_leaf);
+            atomicAdd(&g->self_shadow_tests, (unsigned long long)x_refill); atomicAdd(&g->self_shadow_hits, (unsigned long long)l_refill);
+#endif
+        }
     }
 }
 

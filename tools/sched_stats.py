@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Developer tool: scheduler statistics of the trace kernel (needs a library built with -DWF_SCHED_STATS; counters are re-purposed).
+usage: MCPT_LIB_PATH=build/libmcpt_hip_stats.so python tools/sched_stats.py [spp]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+r = pkg.Renderer(pkg.scenes.cornell_box(800, 800), max_depth=8, flags=4)
+r.render(spp, seed=1); r.sync(); c = r.counters()
+rays = c.rays
+print("rays %.3g  inner: execs/ray %.4f lanes/exec %.1f (steps/ray %.2f) | leaf: execs/ray %.4f lanes/exec %.1f (visits/ray %.2f) | refill execs/ray %.4f free slots/exec %.1f" % (
+    rays, c.shaded_hits / rays, c.box_tests / max(1, c.shaded_hits), c.box_tests / rays, c.texel_fetches / rays, c.tri_tests / max(1, c.texel_fetches),
+    c.tri_tests / rays, c.self_shadow_tests / rays, c.self_shadow_hits / max(1, c.self_shadow_tests)), flush=True)
