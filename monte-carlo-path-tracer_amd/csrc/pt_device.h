@@ -294,8 +294,9 @@ DEV Scatter bsdf_sample(const Bsdf& b, float xi_lobe, float xi1, float xi2) {
     if (!pick_spec) {                                                    // Diffuse lobe sampled
         if (!(b.m_wo.z < 0.f)) {
             const float phi = xi1 * 2.f * PT_PI;
-            const float theta = 0.5f * acosf(1.f - 2.f * xi2);
-            const float st = __sinf(theta), ct = __cosf(theta), sp = __sinf(phi), cp = __cosf(phi);
+            // theta = acos(1 - 2 xi2) / 2 (BSDF.cpp:15-16)  =>  cos theta = sqrt(1 - xi2), sin theta = sqrt(xi2): two v_sqrt_f32 instead of
+            // an acosf expansion and two more sin/cos
+            const float st = __builtin_amdgcn_sqrtf(xi2), ct = __builtin_amdgcn_sqrtf(1.f - xi2), sp = __sinf(phi), cp = __cosf(phi);
             s.wo = mk3(st * cp, st * sp, ct);
             s.f = b.kd * PT_INV_PI;
             s.pdf = fabsf(ct) * PT_INV_PI;

@@ -94,21 +94,20 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f); bool sm_loaded = false;    // item accumulator: fetched only when a path ends
     // one batch of requests for everything an ALIVE slot needs about its traced ray (nearly every slot is ALIVE in steady state)
     // (requested unconditionally so they go out in the same batch as beta / L / ids: one memory round trip for all slot state)
-    const float4 h = ld_s(&pool.hit[slot]), ro4 = ld_s(&pool.ray_o[slot]), rd4 = ld_s(&pool.ray_d[slot]); const double4 og = ld_s(&pool.org64[slot]);
+    const float4 h = ld_s(&pool.hit[slot]), rd4 = ld_s(&pool.ray_d[slot]); const double4 og = ld_s(&pool.org64[slot]);
     const float nl = (float)sc.n_lights;
     const bool correct_t2 = (p.flags & MCPT_FLAG_CORRECT_SHADOW_T2) != 0;
 
     bool terminated = false, emit_extend = false, emit_shadow = false, sum_dirty = false, id_dirty = false;
     bool c_prim = false, c_cont = false, c_self_t = false, c_self_h = false, c_shaded = false;
     uint32_t c_texel = 0;
-    f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1), sh_dir = mk3(0, 0, 1), nee = mk3(0, 0, 0);
-    d3 no64 = mkd(0, 0, 0);
-    float sh_t2 = 0.f; int sh_skip = -1;
+    f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
+    int sh_skip = -1;
 
 #ifdef MCPT_EXPERIMENT_SHADE_NULL     // timing diagnostic: slot-state streaming + regeneration only, no hit processing (image is garbage)
     if (state == SLOT_ALIVE) {
         if (bounce >= 3 || __float_as_int(h.x) < 0) terminated = true;
-        else { no = xyz(ro4); nd = xyz(rd4); no64 = mkd(og.x, og.y, og.z); bounce++; emit_extend = true; c_cont = true; }
+        else { no = mk3((float)og.x, (float)og.y, (float)og.z); nd = xyz(rd4); bounce++; emit_extend = true; c_cont = true; }
     } else if (state == SLOT_DRAIN) terminated = true;
     if (false) do {
         const int tri = -1;
@@ -118,7 +117,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
 #endif
         if (tri < 0) { terminated = true; break; }                                             // Render.cpp:118-119,144-145
         float hu, hv;
-        const f3 prev_p = xyz(ro4), d = xyz(rd4);
+        const f3 d = xyz(rd4);
         // second batch: the light record + its fp64 corners are requested NOW (they depend only on the RNG key), together with
         // the hit triangle's fp64 corners and shading record below -- one memory round trip instead of two
         const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
@@ -149,9 +148,10 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
                 const f3 rad = mk3(mat.radiance[0], mat.radiance[1], mat.radiance[2]);
                 if (prev_mirror) L = L + beta * rad;
                 else {
-                    const f3 dd = prev_p - p32;
-                    const float len = length(dd);
-                    const float cosine = dot(normalize(dd), hs.n);
+                    // Render.cpp:150-152 measures |prev - p| and the cosine along normalize(prev - p): the traced ray IS that segment
+                    // (unit direction d, hit distance h.w), so neither the previous vertex nor a square root is needed
+                    const float len = h.w;
+                    const float cosine = -dot(d, hs.n);
                     float light_pdf = 0.f;
                     if (cosine != 0.f) light_pdf = len * len * rcp(cosine * nl * tri_area(sc, tri));
                     L = L + beta * rad * power_heuristic(prev_pdf, light_pdf);
@@ -177,11 +177,15 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
                 bsdf_eval(bsdf, ls.wo, fx, bpdf);
                 const float cos_theta = fabsf(dot(hs.n, ls.wo));
                 const float weight = power_heuristic(ls.pdf * rcp(nl), bpdf);
-                nee = weight * beta * ls.rad * fx * (cos_theta * rcp(ls.pdf) * nl);                 // Render.cpp:127-129
-                sh_dir = ls.wo; sh_t2 = ls.t2; sh_skip = ls.tri; emit_shadow = true;
+                const f3 nee = weight * beta * ls.rad * fx * (cos_theta * rcp(ls.pdf) * nl);        // Render.cpp:127-129
+                // the shadow ray's payload is final here: store it now rather than carrying 8 registers through bsdf_sample
+                st_s(&pool.sh_d[slot], mk4(ls.wo, ls.t2)); st_s(&pool.nee[slot], mk4(nee, 0.f));
+                sh_skip = ls.tri; emit_shadow = true;
             }
         }
-        no = p32; no64 = p64;                                                                   // both new rays start at the hit point
+        no = p32;                                                                               // both new rays start at the hit point
+        st_s(&pool.org64[slot], make_double4(p64.x, p64.y, p64.z, 0.0));                        // (stored now: frees 6 registers; a path that
+                                                                                                //  ends below simply leaves it unused)
         const Scatter s = bsdf_sample(bsdf, ra.v[3], rb.v[0], rb.v[1]);                         // Render.cpp:133-134
         if (s.pdf == 0.f) {                                                                     // Render.cpp:135-136: path ends, but its last
             state = SLOT_DRAIN;                                                                 // shadow ray is still in flight -> finalise next call
@@ -262,7 +266,9 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         id.y = id.z++; id_dirty = true;
         const Rng4 r = rng_block(id.x, id.y, 0u, p.seed_lo, p.seed_hi);
         const int px = (int)(id.x % (uint32_t)sc.cam.width), py = (int)(id.x / (uint32_t)sc.cam.width);
-        cast_ray(sc.cam, px, py, r.v[0], r.v[1], no64, no, nd);                                 // Render.cpp:64
+        d3 eye64;
+        cast_ray(sc.cam, px, py, r.v[0], r.v[1], eye64, no, nd);                                // Render.cpp:64
+        st_s(&pool.org64[slot], make_double4(eye64.x, eye64.y, eye64.z, 0.0));
         beta = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f); bounce = 0; prev_pdf = 0.f; prev_mirror = false;
         state = SLOT_ALIVE; emit_extend = true; c_prim = true;
     }
@@ -272,8 +278,6 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     st_s(&pool.L[slot], mk4(L, prev_pdf));
     if (emit_extend || emit_shadow) st_s(&pool.ray_o[slot], mk4(no, __int_as_float(sh_skip)));
     st_s(&pool.ray_d[slot], mk4(nd, emit_extend ? 1.f : 0.f));
-    if (emit_extend) st_s(&pool.org64[slot], make_double4(no64.x, no64.y, no64.z, 0.0));
-    if (emit_shadow) { st_s(&pool.sh_d[slot], mk4(sh_dir, sh_t2)); st_s(&pool.nee[slot], mk4(nee, 0.f)); }
     if (sum_dirty && sm_loaded) st_s(&pool.sum[slot], sm);
     if (id_dirty) st_s(&pool.ids[slot], id);
 
@@ -319,7 +323,9 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
 // Block = WF_TRACE_BLOCK (1024) threads = 16 waves sharing one LDS image of the top MCPT_TOP_NODES nodes (64 KB, quarter-major so
 // that lanes reading different nodes spread over the banks) + a 16-entry per-lane stack (64 KB); deeper stack entries (rare)
 // spill to a global overflow area.  One block per CU: 16 waves / CU.
+#ifndef WF_TRACE_BLOCK
 #define WF_TRACE_BLOCK 1024
+#endif
 #ifndef WF_CHUNK_BATCH
 #define WF_CHUNK_BATCH 4
 #endif
