@@ -27,6 +27,7 @@ INTEGRATOR_RECURSIVE_NEE = 1
 FLAG_CORRECT_SHADOW_T2 = 0x1
 FLAG_DETERMINISTIC = 0x2
 FLAG_COUNT_TRAVERSAL = 0x4
+FLAG_GPU_BVH_BUILD = 0x8
 
 
 class Texture(C.Structure):

@@ -1,0 +1,17 @@
+// GPU construction of the binary BVH (bvh_gpu.hip).  Input: one fp32 box per triangle (lo xyz, hi xyz; already rounded outward from
+// the fp64 vertices).  Output: the same arrays the host SAH builder hands to the rest of scene_build.cpp.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "scene_build.h"
+
+struct GpuBvh {
+    std::vector<f4h> nodes;        // 4 per inner node, host builder's layout (scene_build.cpp write_node); node 0 = root
+    std::vector<uint32_t> order;   // leaf order: order[i] = input triangle at position i
+    uint32_t depth = 0, max_leaf = 0;
+    double ms = 0.0;               // wall time incl. upload / download
+};
+
+// Needs n > MCPT_LEAF_MAX and a current HIP device.  Returns false with `err` set on any HIP error.
+bool gpu_build_bvh2(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string& err);

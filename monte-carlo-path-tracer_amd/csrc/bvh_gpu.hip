@@ -1,0 +1,239 @@
+// GPU construction of the binary BVH: the MI355X replacement for BVH::BVH / BVH::build (BVH.cpp:6-54) when the
+// scene is large enough for the host's binned-SAH builder to matter (2.2 s for 4 M triangles).  Linear BVH:
+//
+//   1. morton_kernel     63-bit Morton code (21 bits per axis) of every triangle's box centre inside the centroid bounds
+//   2. rocprim radix sort of (code, triangle) pairs -- the sorted order IS the leaf order of the tree
+//   3. hierarchy_kernel  Karras 2012: every internal node finds its key range and split from the common-prefix lengths of its
+//                        neighbours (equal codes are told apart by their position), all n-1 nodes in parallel
+//   4. refit_kernel      bottom-up: one thread per triangle climbs towards the root; the second thread to arrive at a node
+//                        (atomic counter) owns it, merges the children's boxes and depths, and continues
+//   5. emit_kernel       Karras nodes covering <= MCPT_LEAF_MAX triangles become leaves; the others are compacted (exclusive scan)
+//                        and written in the host builder's 64-B node format (both child boxes in the parent, child codes)
+//
+// Everything downstream (breadth-first renumbering, collapse to the 4-wide quantised tree, triangle streams in leaf order) is the
+// same host code that follows the SAH builder.  Traversal results do not depend on the tree (closest hit = min t), only its cost
+// does: LBVH trees cost ~1.2-1.5x the SAH tree's node visits, so the SAH builder stays the default and this one is opt-in
+// (MCPT_FLAG_GPU_BVH_BUILD).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "bvh_gpu.h"
+#include "device_scene.h"
+
+namespace {
+
+struct DBuf {
+    void* p = nullptr;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+__device__ __forceinline__ uint64_t expand21(uint64_t v) {   // spread 21 bits to every third bit
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ void morton_kernel(const float* __restrict__ boxes, uint32_t n, float3 lo, float3 inv_ext, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* b = boxes + 6 * (size_t)i;
+    const float cx = 0.5f * (b[0] + b[3]), cy = 0.5f * (b[1] + b[4]), cz = 0.5f * (b[2] + b[5]);
+    const float s = 2097152.0f;   // 2^21
+    const uint64_t x = (uint64_t)fminf(fmaxf((cx - lo.x) * inv_ext.x * s, 0.f), s - 1.f);
+    const uint64_t y = (uint64_t)fminf(fmaxf((cy - lo.y) * inv_ext.y * s, 0.f), s - 1.f);
+    const uint64_t z = (uint64_t)fminf(fmaxf((cz - lo.z) * inv_ext.z * s, 0.f), s - 1.f);
+    keys[i] = (expand21(x) << 2) | (expand21(y) << 1) | expand21(z);
+    vals[i] = i;
+}
+
+// common-prefix length of the keys at sorted positions i and j; equal keys are distinguished by their positions (Karras 2012, §4)
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+#define LEAF_BIT 0x80000000u   // child reference: bit 31 set = triangle position in sorted order, else internal node index
+
+__global__ void hierarchy_kernel(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ left, uint32_t* __restrict__ right,
+                                 uint32_t* __restrict__ parent_of_internal, uint32_t* __restrict__ parent_of_leaf,
+                                 uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    first[i] = (uint32_t)lo; last[i] = (uint32_t)hi;
+    if (lo == gamma) { left[i] = LEAF_BIT | (uint32_t)gamma; parent_of_leaf[gamma] = (uint32_t)i; }
+    else { left[i] = (uint32_t)gamma; parent_of_internal[gamma] = (uint32_t)i; }
+    if (hi == gamma + 1) { right[i] = LEAF_BIT | (uint32_t)(gamma + 1); parent_of_leaf[gamma + 1] = (uint32_t)i; }
+    else { right[i] = (uint32_t)(gamma + 1); parent_of_internal[gamma + 1] = (uint32_t)i; }
+}
+
+struct Box6 { float lx, ly, lz, hx, hy, hz; };
+__device__ __forceinline__ Box6 load_tri_box(const float* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t pos) {
+    const float* b = boxes + 6 * (size_t)order[pos];
+    return Box6{b[0], b[1], b[2], b[3], b[4], b[5]};
+}
+__device__ __forceinline__ Box6 merge(const Box6& a, const Box6& b) {
+    return Box6{fminf(a.lx, b.lx), fminf(a.ly, b.ly), fminf(a.lz, b.lz), fmaxf(a.hx, b.hx), fmaxf(a.hy, b.hy), fmaxf(a.hz, b.hz)};
+}
+
+// device-scope loads: a neighbouring record of the same cache line may sit stale in this CU's L1
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ Box6 load_node_box(const Box6* p) {
+    const uint32_t* u = reinterpret_cast<const uint32_t*>(p);
+    return Box6{__uint_as_float(ld_agent(u)), __uint_as_float(ld_agent(u + 1)), __uint_as_float(ld_agent(u + 2)),
+                __uint_as_float(ld_agent(u + 3)), __uint_as_float(ld_agent(u + 4)), __uint_as_float(ld_agent(u + 5))};
+}
+// node_box / node_depth are written by the thread that arrives second at a node and read by whoever arrives second at its parent:
+// the __threadfence() pairs around the counter make those writes visible (same pattern as Karras 2012 §5).
+__global__ void refit_kernel(const float* __restrict__ boxes, const uint32_t* __restrict__ order, int n, const uint32_t* __restrict__ left,
+                             const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent_of_internal,
+                             const uint32_t* __restrict__ parent_of_leaf, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                             uint32_t* __restrict__ arrivals, Box6* node_box, uint32_t* node_depth, uint32_t leaf_max) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t cur = parent_of_leaf[k];
+    for (;;) {
+        __threadfence();
+        if (atomicAdd(&arrivals[cur], 1u) == 0u) return;            // the sibling subtree is not finished yet: its thread will continue
+        __threadfence();
+        const uint32_t l = left[cur], r = right[cur];
+        const Box6 bl = (l & LEAF_BIT) ? load_tri_box(boxes, order, l & ~LEAF_BIT) : load_node_box(node_box + l);
+        const Box6 br = (r & LEAF_BIT) ? load_tri_box(boxes, order, r & ~LEAF_BIT) : load_node_box(node_box + r);
+        const uint32_t dl = (l & LEAF_BIT) ? 0u : ld_agent(node_depth + l), dr = (r & LEAF_BIT) ? 0u : ld_agent(node_depth + r);
+        node_box[cur] = merge(bl, br);
+        // depth in OUTPUT inner nodes: a Karras node spanning <= leaf_max triangles becomes a leaf (depth 0)
+        node_depth[cur] = (last[cur] - first[cur] + 1u > leaf_max) ? 1u + (dl > dr ? dl : dr) : 0u;
+        if (cur == 0u) return;
+        cur = parent_of_internal[cur];
+    }
+}
+
+__global__ void flag_kernel(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, int n_internal, uint32_t leaf_max, uint32_t* __restrict__ is_inner) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_internal) is_inner[i] = (last[i] - first[i] + 1u > leaf_max) ? 1u : 0u;
+}
+
+__device__ __forceinline__ int leaf_code_dev(uint32_t first, uint32_t count) { return ~(int)((first << 3) | count); }
+
+__global__ void emit_kernel(const float* __restrict__ boxes, const uint32_t* __restrict__ order, int n_internal, const uint32_t* __restrict__ left,
+                            const uint32_t* __restrict__ right, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                            const uint32_t* __restrict__ is_inner, const uint32_t* __restrict__ new_id, const Box6* __restrict__ node_box,
+                            uint32_t leaf_max, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal || !is_inner[i]) return;
+    Box6 b[2]; int code[2];
+    const uint32_t ch[2] = {left[i], right[i]};
+    for (int k = 0; k < 2; k++) {
+        const uint32_t c = ch[k];
+        if (c & LEAF_BIT) { b[k] = load_tri_box(boxes, order, c & ~LEAF_BIT); code[k] = leaf_code_dev(c & ~LEAF_BIT, 1u); }
+        else {
+            b[k] = node_box[c];
+            code[k] = is_inner[c] ? (int)new_id[c] : leaf_code_dev(first[c], last[c] - first[c] + 1u);
+        }
+        // same padding rule as the host builder (scene_build.cpp write_node): ~16 ulp of the largest coordinate
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(b[k].lx), fabsf(b[k].hx)), fmaxf(fabsf(b[k].ly), fabsf(b[k].hy))), fmaxf(fabsf(b[k].lz), fabsf(b[k].hz)));
+        const float pad = m * 1e-6f + 1e-30f;
+        b[k].lx -= pad; b[k].ly -= pad; b[k].lz -= pad; b[k].hx += pad; b[k].hy += pad; b[k].hz += pad;
+    }
+    float4* o = out + 4 * (size_t)new_id[i];
+    o[0] = make_float4(b[0].lx, b[0].hx, b[0].ly, b[0].hy);
+    o[1] = make_float4(b[1].lx, b[1].hx, b[1].ly, b[1].hy);
+    o[2] = make_float4(b[0].lz, b[0].hz, b[1].lz, b[1].hz);
+    o[3] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), 0.f, 0.f);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return false; } } while (0)
+
+}  // namespace
+
+bool gpu_build_bvh2(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string& err) {
+    if (n <= (uint32_t)MCPT_LEAF_MAX) { err = "gpu_build_bvh2: needs more than MCPT_LEAF_MAX triangles"; return false; }
+    const auto t0 = std::chrono::steady_clock::now();
+    // centroid bounds on the host: one pass over data the host has just produced (the boxes); everything O(n log n) runs on the device
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) {
+            const float c = 0.5f * (tri_boxes[6 * (size_t)i + a] + tri_boxes[6 * (size_t)i + 3 + a]);
+            if (!(c == c) || std::fabs(c) > 3.0e38f) { err = "gpu_build_bvh2: non-finite triangle bounds"; return false; }
+            lo[a] = std::fmin(lo[a], c); hi[a] = std::fmax(hi[a], c);
+        }
+    float3 dlo = make_float3(lo[0], lo[1], lo[2]);
+    float3 inv = make_float3(hi[0] > lo[0] ? 1.f / (hi[0] - lo[0]) : 0.f, hi[1] > lo[1] ? 1.f / (hi[1] - lo[1]) : 0.f, hi[2] > lo[2] ? 1.f / (hi[2] - lo[2]) : 0.f);
+
+    const int ni = (int)n - 1;
+    DBuf d_boxes, d_k0, d_k1, d_v0, d_v1, d_left, d_right, d_pi, d_pl, d_first, d_last, d_arr, d_nbox, d_depth, d_inner, d_newid, d_tmp, d_out;
+    CK(d_boxes.alloc(sizeof(float) * 6 * (size_t)n));
+    CK(d_k0.alloc(8 * (size_t)n)); CK(d_k1.alloc(8 * (size_t)n)); CK(d_v0.alloc(4 * (size_t)n)); CK(d_v1.alloc(4 * (size_t)n));
+    CK(d_left.alloc(4 * (size_t)ni)); CK(d_right.alloc(4 * (size_t)ni)); CK(d_pi.alloc(4 * (size_t)ni)); CK(d_pl.alloc(4 * (size_t)n));
+    CK(d_first.alloc(4 * (size_t)ni)); CK(d_last.alloc(4 * (size_t)ni)); CK(d_arr.alloc(4 * (size_t)ni)); CK(d_nbox.alloc(sizeof(Box6) * (size_t)ni));
+    CK(d_depth.alloc(4 * (size_t)ni)); CK(d_inner.alloc(4 * (size_t)ni)); CK(d_newid.alloc(4 * (size_t)ni));
+    CK(hipMemcpy(d_boxes.p, tri_boxes, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
+    CK(hipMemset(d_arr.p, 0, 4 * (size_t)ni));
+    CK(hipMemset(d_pi.p, 0, 4 * (size_t)ni));
+
+    const int B = 256;
+    hipLaunchKernelGGL(morton_kernel, dim3((n + B - 1) / B), dim3(B), 0, 0, d_boxes.as<float>(), n, dlo, inv, d_k0.as<uint64_t>(), d_v0.as<uint32_t>());
+    CK(hipGetLastError());
+    size_t tmp_bytes = 0, scan_bytes = 0;
+    CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint32_t>(), d_v1.as<uint32_t>(), (size_t)n, 0u, 63u));
+    CK(rocprim::exclusive_scan(nullptr, scan_bytes, d_inner.as<uint32_t>(), d_newid.as<uint32_t>(), 0u, (size_t)ni, rocprim::plus<uint32_t>()));
+    CK(d_tmp.alloc(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes));
+    CK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint32_t>(), d_v1.as<uint32_t>(), (size_t)n, 0u, 63u));
+    const uint64_t* keys = d_k1.as<uint64_t>(); const uint32_t* order = d_v1.as<uint32_t>();
+    hipLaunchKernelGGL(hierarchy_kernel, dim3((ni + B - 1) / B), dim3(B), 0, 0, keys, (int)n, d_left.as<uint32_t>(), d_right.as<uint32_t>(), d_pi.as<uint32_t>(),
+                       d_pl.as<uint32_t>(), d_first.as<uint32_t>(), d_last.as<uint32_t>());
+    CK(hipGetLastError());
+    hipLaunchKernelGGL(refit_kernel, dim3((n + B - 1) / B), dim3(B), 0, 0, d_boxes.as<float>(), order, (int)n, d_left.as<uint32_t>(), d_right.as<uint32_t>(),
+                       d_pi.as<uint32_t>(), d_pl.as<uint32_t>(), d_first.as<uint32_t>(), d_last.as<uint32_t>(), d_arr.as<uint32_t>(), d_nbox.as<Box6>(),
+                       d_depth.as<uint32_t>(), (uint32_t)MCPT_LEAF_MAX);
+    CK(hipGetLastError());
+    hipLaunchKernelGGL(flag_kernel, dim3((ni + B - 1) / B), dim3(B), 0, 0, d_first.as<uint32_t>(), d_last.as<uint32_t>(), ni, (uint32_t)MCPT_LEAF_MAX, d_inner.as<uint32_t>());
+    CK(hipGetLastError());
+    CK(rocprim::exclusive_scan(d_tmp.p, scan_bytes, d_inner.as<uint32_t>(), d_newid.as<uint32_t>(), 0u, (size_t)ni, rocprim::plus<uint32_t>()));
+    uint32_t last_id = 0, last_flag = 0, depth = 0;
+    CK(hipMemcpy(&last_id, d_newid.as<uint32_t>() + (ni - 1), 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&last_flag, d_inner.as<uint32_t>() + (ni - 1), 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&depth, d_depth.p, 4, hipMemcpyDeviceToHost));                 // root = Karras node 0
+    const uint32_t n_out = last_id + last_flag;
+    CK(d_out.alloc(64 * (size_t)n_out));
+    hipLaunchKernelGGL(emit_kernel, dim3((ni + B - 1) / B), dim3(B), 0, 0, d_boxes.as<float>(), order, ni, d_left.as<uint32_t>(), d_right.as<uint32_t>(),
+                       d_first.as<uint32_t>(), d_last.as<uint32_t>(), d_inner.as<uint32_t>(), d_newid.as<uint32_t>(), d_nbox.as<Box6>(), (uint32_t)MCPT_LEAF_MAX,
+                       d_out.as<float4>());
+    CK(hipGetLastError());
+    out.nodes.resize(4 * (size_t)n_out);
+    out.order.resize(n);
+    CK(hipMemcpy(out.nodes.data(), d_out.p, 64 * (size_t)n_out, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(out.order.data(), order, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    out.depth = depth; out.max_leaf = (uint32_t)MCPT_LEAF_MAX;
+    out.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}

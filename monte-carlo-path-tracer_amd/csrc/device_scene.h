@@ -24,7 +24,7 @@
 
 #define MCPT_LEAF_MAX 2
 #ifndef MCPT_STACK_DEPTH
-#define MCPT_STACK_DEPTH 32        // LDS traversal stack entries per lane (BVH builder guarantees depth <= this)
+#define MCPT_STACK_DEPTH 64        // LDS traversal stack entries per lane of the binary-tree kernels (host SAH trees: depth <= 30; device LBVH trees: <= 63, checked)
 #endif
 #define MCPT_BLOCK 256             // threads per workgroup = 4 waves of 64
 #ifndef MCPT_TOP_NODES

@@ -3,6 +3,7 @@
 #include "../../include/mcpt.h"
 #include "kernels.h"
 #include "scene_build.h"
+#include "bvh_gpu.h"
 #include "wavefront.h"
 
 #include <chrono>
@@ -156,13 +157,32 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if (o.integrator > MCPT_INTEGRATOR_RECURSIVE_NEE) return fail(MCPT_ERR_INVALID_ARG, "unknown integrator");
 
     HostScene hs; std::string err;
-    mcpt_status st = build_host_scene(scene, hs, err);
-    if (st != MCPT_OK) return fail(st, err);
-
     int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) return fail(MCPT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (o.device < 0 || o.device >= ndev) return fail(MCPT_ERR_NO_DEVICE, "device ordinal out of range");
+    hipError_t e = hipSuccess;
+    auto check_device = [&]() -> mcpt_status {
+        e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) return fail(MCPT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+        if (o.device < 0 || o.device >= ndev) return fail(MCPT_ERR_NO_DEVICE, "device ordinal out of range");
+        return MCPT_OK;
+    };
+    mcpt_status st;
+    if (o.flags & MCPT_FLAG_GPU_BVH_BUILD) {                              // the tree is built on the device the context will render on
+        if ((st = check_device()) != MCPT_OK) return st;
+        if ((e = hipSetDevice(o.device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
+        st = build_host_scene(scene, hs, err, [&](const float* boxes, uint32_t n, std::vector<f4h>& nodes, std::vector<int>& order, uint32_t& depth,
+                                                   uint32_t& max_leaf, std::string& berr) {
+            GpuBvh g;
+            if (!gpu_build_bvh2(boxes, n, g, berr)) return false;
+            nodes.swap(g.nodes); order.assign(g.order.begin(), g.order.end()); depth = g.depth; max_leaf = g.max_leaf;
+            return true;
+        });
+        if (st != MCPT_OK) return fail(st, err);
+        if (env_u32("MCPT_VALIDATE_BVH", 0)) { const std::string bad = validate_bvh4(hs); if (!bad.empty()) return fail(MCPT_ERR_HIP, "device-built BVH failed validation: " + bad); }
+    } else {
+        st = build_host_scene(scene, hs, err);
+        if (st != MCPT_OK) return fail(st, err);
+        if ((st = check_device()) != MCPT_OK) return st;
+    }
 
     mcpt_ctx* c = new mcpt_ctx();
     c->device = o.device; c->opts = o; c->width = scene->camera.width; c->height = scene->camera.height;

@@ -62,7 +62,7 @@ public:
 
 private:
     static constexpr int kBins = 16;
-    static constexpr int kMaxDepth = MCPT_STACK_DEPTH - 2;   // inner-node levels; stack holds sentinel + one entry per level
+    static constexpr int kMaxDepth = 30;   // inner-node levels (the traversal stacks hold MCPT_STACK_DEPTH = 64: sentinel + one entry per level)
 
     static int levels_needed(int n) { int l = 0; while ((MCPT_LEAF_MAX << l) < n) l++; return l; }
 
@@ -280,7 +280,7 @@ std::string validate_bvh4(const HostScene& hs) {
     return "";
 }
 
-mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err) {
+mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh) {
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
     if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }
     if (d->camera.width <= 0 || d->camera.height <= 0) { err = "camera width/height must be positive"; return MCPT_ERR_INVALID_ARG; }
@@ -333,9 +333,19 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     // ---- BVH
     auto t0 = std::chrono::steady_clock::now();
     out.nodes.clear();
-    Builder b(bt, out.nodes);
-    b.run();
-    out.bvh_depth = b.depth; out.max_leaf = b.max_leaf;
+    std::vector<int> order;
+    if (custom_bvh && nf > uint32_t(MCPT_LEAF_MAX)) {
+        std::vector<float> boxes(6 * size_t(nf));
+        for (uint32_t f = 0; f < nf; f++)
+            for (int a = 0; a < 3; a++) { boxes[6 * size_t(f) + a] = round_down(bt[f].lo[a], 0.f); boxes[6 * size_t(f) + 3 + a] = round_up(bt[f].hi[a], 0.f); }
+        if (!custom_bvh(boxes.data(), nf, out.nodes, order, out.bvh_depth, out.max_leaf, err)) return MCPT_ERR_HIP;
+        if (order.size() != nf || out.nodes.empty() || out.nodes.size() % 4 != 0) { err = "custom BVH builder returned inconsistent arrays"; return MCPT_ERR_HIP; }
+    } else {
+        Builder b(bt, out.nodes);
+        b.run();
+        out.bvh_depth = b.depth; out.max_leaf = b.max_leaf;
+        order = b.order();
+    }
     {   // Renumber: the first MCPT_TOP_NODES nodes in breadth-first order (= the top ~10 levels, which the trace kernel keeps in
         // LDS), every subtree below them in depth-first order (children next to parents -> cache-line locality in L1/L2).
         const int n_nodes = int(out.nodes.size() / 4);
@@ -368,7 +378,6 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (out.bvh_depth > uint32_t(MCPT_STACK_DEPTH - 1)) { err = "BVH depth exceeds traversal stack"; return MCPT_ERR_BVH_DEPTH; }
     build_bvh4(out);
-    const std::vector<int>& order = b.order();
     std::vector<int> pos_of_face(nf);
     for (uint32_t i = 0; i < nf; i++) pos_of_face[order[i]] = int(i);
 

@@ -2,6 +2,7 @@
 // BVH::BVH / BVH::build (BVH.cpp:6-54).  Output = the flat arrays of device_scene.h, ready for one hipMemcpy each.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/mcpt.h"
@@ -25,9 +26,14 @@ struct HostScene {
     double bvh_build_ms = 0.0;
 };
 
+// Optional replacement for the host SAH builder (bvh_gpu.hip): gets one fp32 box per face (lo xyz, hi xyz, rounded outward) and
+// fills the binary tree in the host builder's node layout, the leaf order, the depth in inner levels and the largest leaf.
+using BvhBuildFn = std::function<bool(const float* boxes, uint32_t n, std::vector<f4h>& nodes, std::vector<int>& order, uint32_t& depth,
+                                      uint32_t& max_leaf, std::string& err)>;
+
 // Validates the description (indices in range, sizes non-zero), flattens faces, collects lights, builds the BVH.
 // Returns MCPT_OK or an error code with `err` filled.
-mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err);
+mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh = nullptr);
 
 // Host-side soundness check of the quantised 4-wide tree (empty string = sound); run by mcpt_check_scene.
 std::string validate_bvh4(const HostScene& hs);

@@ -17,7 +17,7 @@
 
 static void usage() {
     std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
-                 "                          [--deterministic] [--ref-index-order]\n";
+                 "                          [--deterministic] [--ref-index-order] [--gpu-bvh]\n";
 }
 
 int main(int argc, char** argv) {
@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
         else if (a == "--out") out = next(); else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--recursive") integrator = MCPT_INTEGRATOR_RECURSIVE_NEE; else if (a == "--corrected") flags |= MCPT_FLAG_CORRECT_SHADOW_T2;
         else if (a == "--deterministic") flags |= MCPT_FLAG_DETERMINISTIC; else if (a == "--ref-index-order") ref_order = true;
+        else if (a == "--gpu-bvh") flags |= MCPT_FLAG_GPU_BVH_BUILD;
         else if (a == "--check") check_only = true;
         else { usage(); return 2; }
     }

@@ -59,6 +59,15 @@ def test_no_cpu_fallback(pkg):
     assert "status 2" in str(e.value) and "no CPU fallback" in str(e.value)
 
 
+def test_device_bvh_build_flag_also_needs_a_device(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.McptError) as e:
+        pkg.Renderer(pkg.scenes.open_box(8, 8), flags=pkg.FLAG_GPU_BVH_BUILD)
+    assert "status 2" in str(e.value)
+
+
 def test_product_library_does_not_reference_the_oracle(pkg):
     """The shipped library must not link, load or embed anything under oracle/."""
     out = subprocess.check_output(["ldd", pkg.LIB_PATH]).decode()

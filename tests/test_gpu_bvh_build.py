@@ -1,0 +1,108 @@
+"""-m gpu: the device BVH builder (csrc/bvh_gpu.hip, MCPT_FLAG_GPU_BVH_BUILD) behind the same C ABI.
+
+The traversal result does not depend on the tree (closest hit = min t, any hit = exists), so a device-built tree must
+  (a) pass the host-side soundness walk of the quantised 4-wide tree (MCPT_VALIDATE_BVH=1: every triangle referenced once and
+      inside every box on its root path),
+  (b) return the reference's own hits on the reference's own random rays (tests/golden/ref_paths.npz), through both the binary
+      tree (probe kernels) and the 4-wide tree (render),
+  (c) render the image the host-built tree renders, sample for sample (deterministic mode), up to exact-tie pixels."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def paths():
+    with np.load(os.path.join(G, "ref_paths.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _gpu_tree_renderer(pkg, scene, **kw):
+    os.environ["MCPT_VALIDATE_BVH"] = "1"
+    try:
+        return pkg.Renderer(scene, flags=kw.pop("flags", 0) | pkg.FLAG_GPU_BVH_BUILD, **kw)
+    finally:
+        os.environ.pop("MCPT_VALIDATE_BVH", None)
+
+
+def test_device_built_tree_returns_the_reference_hits(pkg, paths):
+    p = paths
+    r = _gpu_tree_renderer(pkg, pkg.scenes.cornell_box_small(64, 64))
+    i = r.info()
+    assert i.n_tris == pkg.scenes.cornell_box_small(64, 64).n_faces and 1 <= i.bvh_depth <= 63 and i.max_leaf <= 2
+    t, tri, u, v = r.probe_trace(p["cs_ray_o"], p["cs_ray_d"])
+    anyh = r.probe_trace(p["cs_ray_o"], p["cs_ray_d"], t2=p["cs_ray_t2"], any_hit=True)[1]
+    r.close()
+    ref_tri = p["cs_ray_rec"][:, 11].astype(np.int32); ref_hit = p["cs_ray_hit"] == 1
+    same = (tri == np.where(ref_hit, ref_tri, -1))
+    assert same.mean() >= 0.999, same.mean()
+    ok = same & ref_hit
+    assert np.allclose(t[ok], p["cs_ray_rec"][ok, 0], rtol=2e-5, atol=2e-6)
+    assert (anyh == p["cs_ray_any"]).mean() >= 0.999
+
+
+@pytest.mark.parametrize("name,kw,res,depth", [("cornell-box-small", {}, (48, 48), 5), ("veach-mis", {"light_lon": 12, "light_lat": 6, "plate_cells": 4}, (64, 36), 0),
+                                               ("bathroom2", {"detail": 24, "tex_size": 32}, (64, 36), 6)])
+def test_device_and_host_trees_render_the_same_samples(pkg, name, kw, res, depth):
+    scene = pkg.scenes.SCENES[name](*res, **kw)
+    imgs = []
+    for gpu_tree in (False, True):
+        if gpu_tree: r = _gpu_tree_renderer(pkg, scene, max_depth=depth, flags=pkg.FLAG_DETERMINISTIC)
+        else: r = pkg.Renderer(scene, max_depth=depth, flags=pkg.FLAG_DETERMINISTIC)
+        r.render(16, seed=21); imgs.append(r.read_accum()); r.close()
+    a, b = imgs
+    assert np.array_equal(a[..., 3], b[..., 3])                                  # sample counts
+    differ = np.any(a[..., :3] != b[..., :3], axis=-1)
+    # identical arithmetic per ray => identical samples, except where two triangles tie exactly (shared edges) or an any-hit ray
+    # has several occluders and the trees find different ones first (same verdict)
+    assert differ.mean() <= 0.01, differ.mean()
+    assert abs(a[..., :3].mean() - b[..., :3].mean()) <= 2e-3 * a[..., :3].mean()
+
+
+def test_device_builder_on_awkward_geometry(pkg):
+    """Huge coordinate offsets, tiny and huge triangles side by side, flat boxes, many identical centroids (equal Morton codes)."""
+    rng = np.random.RandomState(11)
+    base = pkg.scenes.open_box(8, 8)
+    n = 3000
+    centres = rng.uniform(-1, 1, (n, 3)) * np.array([1e3, 1.0, 1e-3]) + np.array([5e4, -3.0, 0.25])
+    size = 10.0 ** rng.uniform(-5, 1, (n, 1, 1))
+    tri = centres[:, None, :] + size * rng.normal(size=(n, 3, 3))
+    tri[::7, :, 1] = tri[::7, :1, 1]
+    tri[1000:1400] = tri[1000]                                                    # 400 copies of one triangle
+    v = np.concatenate([base.vertex, tri.reshape(-1, 3)])
+    nrm = np.concatenate([base.normal, np.tile([[0.0, 1.0, 0.0]], (3 * n, 1))])
+    tc = np.concatenate([base.texcoord, np.zeros((3 * n, 2))])
+    off = base.vertex.shape[0]
+    f = np.zeros((n, 3, 4), np.int32)
+    for k in range(3):
+        f[:, k, 0] = f[:, k, 1] = f[:, k, 2] = off + 3 * np.arange(n) + k
+    scene = pkg.scenes.SceneData("stress", v, nrm, tc, np.concatenate([base.face, f]), base.materials, base.camera)
+    rg = _gpu_tree_renderer(pkg, scene); rh = pkg.Renderer(scene)
+    assert rg.info().n_tris == base.n_faces + n and rg.info().bvh_depth <= 63
+    m = 20000
+    o = rng.uniform(-1, 1, (m, 3)) * np.array([1.2e3, 4.0, 4.0]) + np.array([5e4, -3.0, 0.25])
+    tgt = centres[rng.randint(0, n, m)] + rng.normal(size=(m, 3)) * 0.5
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tg, ig, _, _ = rg.probe_trace(o, d); th, ih, _, _ = rh.probe_trace(o, d)
+    rg.close(); rh.close()
+    assert (ih >= 0).mean() > 0.2                                                 # the rays do hit things
+    assert ((ig >= 0) == (ih >= 0)).all()
+    hit = ih >= 0
+    assert np.array_equal(tg[hit], th[hit])                                       # same closest distance, bit for bit
+    # the triangle may differ only between exact ties (the 400 coincident copies)
+    assert ((ig == ih) | ((ig >= base.n_faces + 1000) & (ig < base.n_faces + 1400))).all()
+
+
+def test_device_builder_is_faster_on_a_large_scene(pkg):
+    scene = pkg.scenes.bathroom_stress(64, 36, detail=160, tex_size=16)          # 0.59 M triangles
+    rh = pkg.Renderer(scene); ih = rh.info(); rh.close()
+    rg = _gpu_tree_renderer(pkg, scene); ig = rg.info()
+    rg.render(4, seed=3); a = rg.read_accum(); rg.close()
+    assert np.isfinite(a).all() and (a[..., 3] == 4).all()
+    print("\nBVH build, %d triangles: host SAH %.0f ms (depth %d, %d nodes) | device LBVH %.0f ms (depth %d, %d nodes)" % (
+        ih.n_tris, ih.bvh_build_ms, ih.bvh_depth, ih.n_nodes, ig.bvh_build_ms, ig.bvh_depth, ig.n_nodes))
+    assert ig.bvh_build_ms < ih.bvh_build_ms

@@ -6,7 +6,7 @@ import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()
 t0 = time.time(); scene = pkg.scenes.bathroom_stress(3840, 2160, detail=420); print("scene gen %.1f s, %d tris" % (time.time() - t0, scene.n_faces), flush=True)
-t0 = time.time(); r = pkg.Renderer(scene, max_depth=16); i = r.info()
+t0 = time.time(); r = pkg.Renderer(scene, max_depth=16, flags=int(os.environ.get("MCPT_FLAGS", "0"))); i = r.info()
 print("create %.1f s: nodes %d depth %d bvh %.0f ms, device %.2f GB" % (time.time() - t0, i.n_nodes, i.bvh_depth, i.bvh_build_ms, i.device_bytes / 1e9), flush=True)
 r.render(2, seed=1); r.sync(); r.reset_counters()
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
