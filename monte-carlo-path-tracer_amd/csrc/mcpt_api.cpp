@@ -428,11 +428,21 @@ mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t fir
     uint32_t spi = ctx->opts.samples_per_item;
     if (ctx->opts.flags & MCPT_FLAG_DETERMINISTIC) spi = spp;               // one lane owns a pixel for the whole call
     else if (spi == 0) {
-        // auto: long enough that per-item overheads (film atomics, tail of an item) vanish, short enough that there are
-        // many more items than lanes/slots so the work balances across the chip
-        spi = 64;
-        const uint64_t want_items = ctx->use_wavefront ? 16ull * ctx->lanes[0].pool.P * ctx->lanes.size() / 64 : 256ull * 16 * 16;   // >= 16 items per slot: short ramp-down tail
-        while (spi > 8 && tiles * ((spp + spi - 1) / spi) < want_items) spi >>= 1;
+        if (ctx->use_wavefront) {
+            // auto: one sample per item unless (a) the image is so small that many pool slots would hammer the same pixel's film
+            // atomics at once, or (b) the item count would overflow the cursor range.  Short items keep the end-of-render drain
+            // short (a slot works its item off sample after sample: 8-sample items cost 2.7 % at 1024 spp on the bench workload)
+            // and cost nothing any more now that items come from sharded cursors with one atomic per block.
+            const uint64_t slots = uint64_t(ctx->lanes[0].pool.P) * ctx->lanes.size(), pixels = uint64_t(ctx->width) * ctx->height;
+            spi = 1;
+            while (spi < 64 && slots > pixels * 16ull * spi) spi <<= 1;
+            while (tiles * ((spp + spi - 1) / spi) > 0x3ffffffull && spi < spp) spi <<= 1;
+        } else {
+            // megakernel: long enough that per-item overheads vanish, short enough that the work balances across the chip
+            spi = 64;
+            const uint64_t want_items = 256ull * 16 * 16;
+            while (spi > 8 && tiles * ((spp + spi - 1) / spi) < want_items) spi >>= 1;
+        }
         if (spi > spp) spi = spp;
     }
     if (spi > spp) spi = spp;

@@ -23,4 +23,5 @@ for k in range(rep):
 print("%-40s %s tris=%d nodes=%d depth=%d bvh %.0f ms  spp=%d  best %.2f ms  %.1f Mray/s  %.1f Mpath/s  rays/path %.2f" % (
     os.path.basename(os.environ.get("MCPT_LIB_PATH", "default")), name, i.n_tris, i.n_nodes, i.bvh_depth, i.bvh_build_ms, spp, best,
     c.rays / best / 1e3, c.paths / best / 1e3, c.rays / c.paths), flush=True)
+print("   iterations %d launches %d" % (c.iterations, c.launches))
 if c.box_tests: print("   box/ray %.2f tri/ray %.2f" % (c.box_tests / c.rays, c.tri_tests / c.rays))
