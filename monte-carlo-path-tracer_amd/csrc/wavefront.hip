@@ -7,13 +7,14 @@
 //
 //   wf_shade_kernel  one lane per slot, every lane busy: consumes the hit of the slot's extend ray (emitter MIS, Russian
 //                    roulette, termination, film write, regeneration of the next camera ray) and produces the next
-//                    extend ray + at most one shadow ray (appended to a compact queue with one atomic per wave).
-//   wf_trace_kernel  persistent waves over the ray list [P extend slots | n_shadow queue entries]; closest-hit and any-hit
-//                    rays share one traversal loop.  Each wave schedules itself with __ballot/__popcll: it runs the
-//                    inner-node block while most lanes sit at inner nodes, the leaf block once enough lanes wait at a
-//                    leaf, and the refill block (write results back, pull fresh rays from a wave-private chunk of the
-//                    queue) once enough lanes are idle -- so the expensive blocks execute with well-packed lanes.
-//                    ~56 VGPRs -> LDS (32-entry per-lane stack) is the occupancy limit: 5 blocks = 20 waves / CU.
+//                    extend ray + at most one shadow ray (atomic-free queue: block b owns entries [256 b, 256 b + n)).
+//   wf_trace_kernel  persistent waves over the ray list [P extend slots | per-block shadow queues]; closest-hit and any-hit
+//                    rays share one traversal loop over the 4-wide quantised tree.  Each wave schedules itself with
+//                    __ballot/__popcll: it runs the inner-node block while most lanes sit at inner nodes, the leaf block
+//                    once enough lanes wait at a leaf, and the refill block (write results back, pull fresh rays from a
+//                    wave-private chunk of the list) once enough lanes are idle -- so the expensive blocks execute with
+//                    well-packed lanes.  64 VGPRs; 1024-thread blocks with 64 KB of LDS (top tree levels + per-lane stack).
+// DESIGN.md §5 has the measurements behind each of these choices.
 #include "pt_device.h"
 #include "wavefront.h"
 
@@ -320,9 +321,10 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
 // ====================================================================================================== trace
 // BVH_node::hit / has_hit (BVH.cpp:95-136), AABB::Intersection (AABB.cpp:25-36), Triangle::hit / isIntersect
 // (Triangle.cpp:48-106) for the whole ray list of one iteration.  Acceptance rules: see bvh_traverse in pt_device.h.
-// Block = WF_TRACE_BLOCK (1024) threads = 16 waves sharing one LDS image of the top MCPT_TOP_NODES nodes (64 KB, quarter-major so
-// that lanes reading different nodes spread over the banks) + a 16-entry per-lane stack (64 KB); deeper stack entries (rare)
-// spill to a global overflow area.  One block per CU: 16 waves / CU.
+// Block = WF_TRACE_BLOCK (1024) threads = 16 waves sharing one LDS image of the top MCPT_TOP_NODES (256) nodes (16 KB, quarter-major
+// so that lanes reading different nodes spread over the banks) + a WF_LDS_STACK (12)-entry per-lane stack (48 KB); deeper stack
+// entries (rare) spill to a global overflow area sized from the tree's depth.  Two blocks fit per CU; the host launches fewer when a
+// second sub-pipeline shares the GPU (mcpt_api.cpp).
 #ifndef WF_TRACE_BLOCK
 #define WF_TRACE_BLOCK 1024
 #endif
@@ -532,15 +534,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #ifndef WF_SCHED_STATS
                 if (COUNT) n_box += (uint32_t)__popc(valid);
 #endif
-#ifdef WF_EXP_VALU   // diagnostic: WF_EXP_VALU extra dependent FMAs per inner step (is the kernel VALU-bound?)
-                { float dm = ax; for (int q = 0; q < WF_EXP_VALU; q++) dm = fmaf(dm, 1.0000001f, ay); if (dm == 12345.678f) key0 = 0.f; }
-#endif
                 int cd0 = __float_as_int(D.x), cd1 = __float_as_int(D.y), cd2 = __float_as_int(D.z), cd3 = __float_as_int(D.w);
 #define WF_CSWAP(KA, CA, KB, CB) { const bool sw = KB < KA; const float tk = sw ? KB : KA; KB = sw ? KA : KB; KA = tk; const int tc = sw ? CB : CA; CB = sw ? CA : CB; CA = tc; }
-                WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2)
-#ifndef WF_PARTIAL_SORT
-                WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
-#endif
+                WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2) WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
 #undef WF_CSWAP
                 const float inf = __builtin_inff();
                 const int h1 = key1 < inf, h2 = key2 < inf, h3 = key3 < inf;      // sorted: hits are a prefix
