@@ -100,7 +100,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    os.environ["MCPT_TIME_KERNELS"] = "1"       # HIP-event pair around every kernel launch, on the launch stream
+    # HIP events around both kernels of every 8th pipeline iteration, recorded on the launch stream inside the timed region (every
+    # iteration costs ~3 % of the step in event packets; the sampled mean agrees with rocprofv3's all-launch average, see profiles/)
+    os.environ.setdefault("MCPT_TIME_KERNELS", "8")
     mg = __import__("importlib").import_module("mcpt_amd.multigpu")
     scene = pkg.scenes.cornell_box(WIDTH, HEIGHT)
     r = pkg.Renderer(scene, max_depth=DEPTH, device=local)
@@ -139,8 +141,9 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- kernel durations: the library brackets every launch of the timed region with HIP events recorded on the launch
-        # stream (torch's current stream, bound above); *_ms_total sum them since reset_counters().  Dominant kernel =
+        # ---- kernel durations: the library brackets the launches of every MCPT_TIME_KERNELS-th iteration of the timed region with HIP
+        # events recorded on the launch stream (forked from torch's current stream, bound above); *_ms_total = sampled mean x launches
+        # since reset_counters().  Dominant kernel =
         # wf_trace_kernel (BVH traversal); one launch of it per pipeline iteration.
         launches = max(1, c.iterations)
         trace_ms = c.trace_ms_total / launches

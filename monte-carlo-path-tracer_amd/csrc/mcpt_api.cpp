@@ -52,14 +52,14 @@ struct mcpt_ctx {
         std::vector<hipEvent_t> k_ev;      // per-kernel event chain (only with detailed timing)
         hipStream_t stream = nullptr;
         hipEvent_t done_ev = nullptr;
-        uint64_t last_iterations = 0;
+        uint64_t last_iterations = 0, last_timed = 0;
     };
     std::vector<WfLane> lanes;
     hipEvent_t fork_ev = nullptr;
     WaveTuning tune{};
     uint32_t trace_grid = 0;
     int n_cus = 0;
-    bool time_kernels = false;
+    uint32_t time_kernels = 0;          // MCPT_TIME_KERNELS=N: bracket the two kernels of every Nth iteration with HIP events (0 = off)
     double last_trace_ms = 0.0, total_trace_ms = 0.0, last_shade_ms = 0.0, total_shade_ms = 0.0;
     uint64_t total_iterations = 0;
 };
@@ -217,7 +217,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         if (P < 2048) P = 2048;
         c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
         c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0);
-        c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0) != 0;
+        c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0);
         if (c->use_wavefront) {
             uint32_t n_lanes = env_u32("MCPT_WF_LANES", 2);
             if (n_lanes < 1) n_lanes = 1;
@@ -300,14 +300,18 @@ static mcpt_status resolve_timing(mcpt_ctx* c) {
             double sh = 0.0, tr = 0.0;
             for (auto& L : c->lanes) {
                 c->total_iterations += L.last_iterations;
-                if (c->time_kernels)
-                    for (uint64_t i = 0; i < L.last_iterations; i++) {
+                if (c->time_kernels && L.last_timed) {                       // sampled iterations stand for all of them
+                    double s_ = 0.0, t_ = 0.0;
+                    for (uint64_t i = 0; i < L.last_timed; i++) {
                         float a_ = 0.f, b_ = 0.f;
-                        HIP_TRY(hipEventElapsedTime(&a_, L.k_ev[2 * i], L.k_ev[2 * i + 1]));
-                        HIP_TRY(hipEventElapsedTime(&b_, L.k_ev[2 * i + 1], L.k_ev[2 * i + 2]));
-                        sh += a_; tr += b_;
+                        HIP_TRY(hipEventElapsedTime(&a_, L.k_ev[3 * i], L.k_ev[3 * i + 1]));
+                        HIP_TRY(hipEventElapsedTime(&b_, L.k_ev[3 * i + 1], L.k_ev[3 * i + 2]));
+                        s_ += a_; t_ += b_;
                     }
-                L.last_iterations = 0;
+                    const double scale = double(L.last_iterations) / double(L.last_timed);
+                    sh += s_ * scale; tr += t_ * scale;
+                }
+                L.last_iterations = 0; L.last_timed = 0;
             }
             c->last_shade_ms = sh; c->last_trace_ms = tr; c->total_shade_ms += sh; c->total_trace_ms += tr;
         }
@@ -352,8 +356,8 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
         HIP_TRY(hipMemsetAsync(r.pool.ids, 0, size_t(r.pool.P) * 16, L.stream));
         HIP_TRY(hipMemsetAsync(r.pool.sum, 0, size_t(r.pool.P) * 16, L.stream));
     }
-    auto k_event = [&](mcpt_ctx::WfLane& L, Run& r) -> hipError_t {
-        if (!ctx->time_kernels) return hipSuccess;
+    auto k_event = [&](mcpt_ctx::WfLane& L, Run& r, bool timed) -> hipError_t {
+        if (!timed) return hipSuccess;
         if (r.kev == L.k_ev.size()) { hipEvent_t ev; hipError_t e = hipEventCreate(&ev); if (e != hipSuccess) return e; L.k_ev.push_back(ev); }
         return hipEventRecord(L.k_ev[r.kev++], L.stream);
     };
@@ -387,10 +391,12 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
             if (!r.active || r.done) continue;
             mcpt_ctx::WfLane& L = ctx->lanes[k];
             IterCtl* ctl = static_cast<IterCtl*>(L.ctl_buf.p);
-            HIP_TRY(k_event(L, r));
+            const bool timed = ctx->time_kernels && r.it % ctx->time_kernels == 0;
+            HIP_TRY(k_event(L, r, timed));
             HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_items, ctx->accum, cnt, L.stream));
-            HIP_TRY(k_event(L, r));
+            HIP_TRY(k_event(L, r, timed));
             HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(L.ovf_buf.p), L.stream));
+            HIP_TRY(k_event(L, r, timed));
             r.it++;
             if (r.it % CHECK == 0) {
                 mcpt_status ps = poll(L, r, r.issued - r.seen >= 2); if (ps != MCPT_OK) return ps;   // at most 2 checks (8 iterations) ahead
@@ -409,8 +415,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
     for (uint32_t k = 0; k < n_lanes; k++) {
         if (!runs[k].active) continue;
         mcpt_ctx::WfLane& L = ctx->lanes[k];
-        HIP_TRY(k_event(L, runs[k]));
-        L.last_iterations = runs[k].it;
+        L.last_iterations = runs[k].it; L.last_timed = runs[k].kev / 3;
         HIP_TRY(hipEventRecord(L.done_ev, L.stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, L.done_ev, 0));            // join: the caller's stream continues after every sub-pipeline
     }
