@@ -223,10 +223,14 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             if (n_lanes < 1) n_lanes = 1;
             if (o.flags & MCPT_FLAG_DETERMINISTIC) n_lanes = 1;          // one owner per pixel, plain stores
             // Persistent trace grid.  One sub-pipeline: fill every CU (2 blocks = 32 waves).  Two: the trace of one runs beside the
-            // shade (or trace) of the other, and measured on MI355X the pair is fastest with ~12 trace waves per CU (grid = 3/4 of the
-            // CUs: 594 vs 617 ms at 1/CU and 662 ms at 2/CU on the bench workload) -- the rest of each CU's wave slots go to shade.
+            // shade (or trace) of the other.  While the traversal data (4-wide nodes + triangle records) is cache-resident the pair is
+            // fastest with ~12 trace waves per CU -- grid = 3/4 of the CUs: 594 vs 617 ms at 1/CU and 662 ms at 2/CU on the bench
+            // workload (3.3 MB), 629 vs 646 ms at 7.7 MB -- the rest of each CU's wave slots go to shade.  Once it spills out of L2
+            // the trace kernel is the longer pole and wants every slot: 345 vs 366 ms at 48 MB, 838 vs 904 ms at 350 MB.
             const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0));
-            c->trace_grid = n_lanes > 1 ? std::max(1u, uint32_t(c->n_cus) * 3u / 4u) : uint32_t(c->n_cus) * per_cu;
+            const size_t traversal_bytes = hs.nodes4.size() * sizeof(f4h) + hs.tri_isect.size() * sizeof(f4h);
+            const bool cache_resident = traversal_bytes <= (size_t(16) << 20);
+            c->trace_grid = (n_lanes > 1 && cache_resident) ? std::max(1u, uint32_t(c->n_cus) * 3u / 4u) : uint32_t(c->n_cus) * per_cu;
             c->trace_grid = std::min(env_u32("MCPT_WF_GRID", c->trace_grid), uint32_t(c->n_cus) * per_cu);
             if ((e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
             c->lanes.resize(n_lanes);
