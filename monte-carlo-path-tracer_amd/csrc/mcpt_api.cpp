@@ -213,7 +213,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         c->n_cus = prop.multiProcessorCount;
         const char* pipe = std::getenv("MCPT_PIPELINE");
         c->use_wavefront = !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS;
-        uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 22);
+        uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 23);
         if (P < 2048) P = 2048;
         c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
         c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0);
@@ -444,7 +444,7 @@ mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t fir
             // and cost nothing any more now that items come from sharded cursors with one atomic per block.
             const uint64_t slots = uint64_t(ctx->lanes[0].pool.P) * ctx->lanes.size(), pixels = uint64_t(ctx->width) * ctx->height;
             spi = 1;
-            while (spi < 64 && slots > pixels * 16ull * spi) spi <<= 1;
+            while (spi < 64 && slots > pixels * 32ull * spi) spi <<= 1;
             while (tiles * ((spp + spi - 1) / spi) > 0x3ffffffull && spi < spp) spi <<= 1;
         } else {
             // megakernel: long enough that per-item overheads vanish, short enough that the work balances across the chip

@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     if (lane == 0) {
         DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1));
         if (ma) ctl->any_active[cur] = 1u;
+#ifndef WF_SCHED_STATS
         if (m_term) atomicAdd(&g->paths, (unsigned long long)__popcll(m_term));
+#endif
         if (m_prim) atomicAdd(&g->rays_primary, (unsigned long long)__popcll(m_prim));
         if (m_cont) atomicAdd(&g->rays_continuation, (unsigned long long)__popcll(m_cont));
         if (ms) atomicAdd(&g->rays_shadow, (unsigned long long)__popcll(ms));
@@ -354,6 +356,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     const int n_top = sc.n_nodes4 < MCPT_TOP_NODES ? sc.n_nodes4 : MCPT_TOP_NODES;
     for (int i = threadIdx.x; i < 4 * n_top; i += WF_TRACE_BLOCK) s_top[(i & 3) * MCPT_TOP_NODES + (i >> 2)] = sc.nodes4[i];
     __syncthreads();
+#ifdef WF_SCHED_STATS
+    const unsigned long long t_start = wall_clock64();
+#endif
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = pool.P;
     // Ray list = 2 * P / 256 chunks: chunk c < P/256 holds the extend rays of slots [256 c, 256 c + 256); chunk P/256 + b holds the
@@ -572,6 +577,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
         if (lane == 0) {
             DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1)); atomicAdd(&g->box_tests, b); atomicAdd(&g->tri_tests, t);
 #ifdef WF_SCHED_STATS   // tools/sched_stats.py: the shade-side counters are re-purposed in this diagnostic build
+            atomicAdd(&g->paths, wall_clock64() - t_start);            // wave lifetime in 10-ns ticks
             atomicAdd(&g->shaded_hits, (unsigned long long)x_inner); atomicAdd(&g->texel_fetches, (unsigned long long)x_leaf);
             atomicAdd(&g->self_shadow_tests, (unsigned long long)x_refill); atomicAdd(&g->self_shadow_hits, (unsigned long long)l_refill);
 #endif
