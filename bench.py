@@ -158,7 +158,11 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):            # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_passes.sh), same workload
-            traffic = json.load(open(tpath)).get("wf_trace_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))            # PMC counters cannot be collected inside this process: measured per ray by the
+            if tj.get("wf_trace_kernel_hbm_bytes_per_ray"):   # committed rocprofv3 passes, scaled by this run's rays per launch
+                traffic = int(tj["wf_trace_kernel_hbm_bytes_per_ray"] * rays_per_launch)
+            else:
+                traffic = tj.get("wf_trace_kernel_hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": "wf_trace_kernel<false>", "kernel_ms": round(trace_ms, 4), "launches_per_step": round(launches / max(1, args.steps), 1),

@@ -30,5 +30,11 @@ j = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (
      "wf_trace_kernel_hbm_bytes_per_launch": per_launch("wf_trace"),
      "wf_shade_kernel_hbm_bytes_per_launch": per_launch("wf_shade"),
      "wf_trace_kernel_uncorrected_bytes_per_launch": per_launch("wf_trace", False)}
+# per traced ray: the PMC run renders 8 + 1024 spp of the bench workload; rays per path from the bench line of the same bundle
+bj = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+rays = (8 + 1024) * 800 * 800 * bj["rays_per_path"]
+j["rays_in_pmc_run"] = int(rays)
+j["wf_trace_kernel_hbm_bytes_per_ray"] = round((vals["wf_trace"]["FETCH_SIZE"] * 2 + vals["wf_trace"]["WRITE_SIZE"]) * 1024 / rays, 2)
+j["wf_shade_kernel_hbm_bytes_per_ray"] = round((vals["wf_shade"]["FETCH_SIZE"] * 2 + vals["wf_shade"]["WRITE_SIZE"]) * 1024 / rays, 2)
 json.dump(j, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
 print(json.dumps(j, indent=1))
