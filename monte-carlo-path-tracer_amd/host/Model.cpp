@@ -5,6 +5,7 @@
 // Face corners follow Wavefront semantics v/vt/vn; `reference_index_order` reproduces the reference's reading of the
 // second index as the NORMAL and the third as the TEXCOORD (SURVEY A-14) for files that were authored against it.
 #include "Model.h"
+#include "Jpeg.h"
 
 #include <cmath>
 #include <cstdio>
@@ -77,12 +78,16 @@ bool load_ppm(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
 }
 }  // namespace
 
-Texture::Texture(const std::string& filename) {
+bool load_image_rgb8(const std::string& filename, int& w, int& h, std::vector<unsigned char>& rgb) {
     std::ifstream in(filename, std::ios::binary);
     std::vector<unsigned char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    return !bytes.empty() && (load_png(bytes, w, h, rgb) || load_jpeg(bytes, w, h, rgb) || load_ppm(bytes, w, h, rgb));
+}
+
+Texture::Texture(const std::string& filename) {
     std::vector<unsigned char> rgb; int w = 0, h = 0;
-    if (bytes.empty() || !(load_png(bytes, w, h, rgb) || load_ppm(bytes, w, h, rgb))) {
-        std::cerr << "Error: cannot decode texture (8-bit PNG or binary PPM expected): " << filename << std::endl;
+    if (!load_image_rgb8(filename, w, h, rgb)) {
+        std::cerr << "Error: cannot decode texture (8-bit PNG, baseline JPEG or binary PPM expected): " << filename << std::endl;
         ok = false; image_color.push_back(Color3f{0.5f, 0.5f, 0.5f}); return;
     }
     image_w = w; image_h = h;

@@ -13,6 +13,9 @@ struct dvec2 { double x = 0, y = 0; };
 struct Color3f { float x = 0, y = 0, z = 0; };
 typedef std::array<std::array<int, 4>, 3> imat3x4;   // per corner {v_idx, vn_idx, vt_idx, material_idx} (model.h:57)
 
+// 8-bit RGB pixels of a PNG (non-interlaced, 8 bit), baseline JPEG or binary PPM file, row 0 = top of the image
+bool load_image_rgb8(const std::string& filename, int& w, int& h, std::vector<unsigned char>& rgb);
+
 class Texture {                                       // model.h:21-30
 public:
     explicit Texture(const std::string& filename);   // 8-bit PNG (non-interlaced) or binary PPM; texels -> (c/255)^2.2 like stbi_loadf

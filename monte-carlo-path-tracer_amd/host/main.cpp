@@ -17,11 +17,21 @@
 
 static void usage() {
     std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
-                 "                          [--deterministic] [--ref-index-order] [--gpu-bvh]\n";
+                 "                          [--deterministic] [--ref-index-order] [--gpu-bvh] [--check]\n"
+                 "       mcpt_cli --decode-image texture.(png|jpg|ppm) out.ppm\n";
 }
 
 int main(int argc, char** argv) {
     if (argc < 2) { usage(); return 2; }
+    if (std::string(argv[1]) == "--decode-image") {              // host-only helper: texture file -> binary PPM (what map_Kd textures decode to)
+        if (argc != 4) { usage(); return 2; }
+        int w = 0, h = 0; std::vector<unsigned char> rgb;
+        if (!load_image_rgb8(argv[2], w, h, rgb)) { std::cerr << "Error: cannot decode " << argv[2] << std::endl; return 1; }
+        FILE* f = std::fopen(argv[3], "wb");
+        if (!f) return 1;
+        std::fprintf(f, "P6\n%d %d\n255\n", w, h); std::fwrite(rgb.data(), 1, rgb.size(), f); std::fclose(f);
+        return 0;
+    }
     std::string filename = argv[1], out;
     uint32_t spp = 64, batch = 0, depth = 0, gpus = 1; uint64_t seed = 20251004; uint32_t flags = 0, integrator = 0; bool ref_order = false, check_only = false;
     for (int i = 2; i < argc; i++) {

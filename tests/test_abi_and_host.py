@@ -186,3 +186,53 @@ def test_cpp_host_loader_reads_the_reference_file_formats(pkg, tmp_path):
     assert np.isclose(j["sum_tex"], tex, rtol=1e-4)               # (c/255)^2.2 texels, constant Kd for untextured materials
     st, info, _ = pkg.check_scene(s)
     assert (j["n_tris"], j["n_lights"], j["n_nodes"], j["bvh_depth"]) == (info.n_tris, info.n_lights, info.n_nodes, info.bvh_depth)
+
+
+def test_cpp_host_loader_decodes_jpeg_textures(pkg, tmp_path):
+    """host/Jpeg.cpp (baseline JPEG written from T.81) against libjpeg-turbo (Pillow): 4:4:4 / 4:2:2 / 4:2:0, odd sizes, grey,
+    restart intervals, optimised Huffman tables; progressive files are refused.  `mcpt_cli --decode-image` is host-only."""
+    Image = pytest.importorskip("PIL.Image")
+    cli = os.path.join(ROOT, "monte-carlo-path-tracer_amd", "csrc", "mcpt_cli")
+    rng = np.random.RandomState(3)
+
+    def picture(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 120 * np.sin(x / 9.0 + y / 23.0), 127 + 120 * np.cos(x / 17.0 - y / 5.0), (x * 3 + y * 5) % 256], -1)
+        return np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+
+    def read_ppm(path):
+        d = open(path, "rb").read(); parts = d.split(b"\n", 3); w, h = map(int, parts[1].split())
+        return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
+
+    cases = [("444", (64, 48), dict(quality=92, subsampling=0)), ("420", (67, 45), dict(quality=90, subsampling=2)),
+             ("422", (130, 33), dict(quality=85, subsampling=1)), ("grey", (40, 40), dict(quality=90)),
+             ("rst", (100, 60), dict(quality=90, subsampling=2, restart_marker_blocks=3)), ("opt", (96, 96), dict(quality=95, subsampling=2, optimize=True))]
+    for name, (w, h), kw in cases:
+        a = picture(w, h)
+        jpg = str(tmp_path / (name + ".jpg")); out = str(tmp_path / (name + ".ppm"))
+        Image.fromarray(a[..., 0] if name == "grey" else a).save(jpg, **kw)
+        subprocess.check_call([cli, "--decode-image", jpg, out])
+        mine = read_ppm(out).astype(int); ref = np.asarray(Image.open(jpg).convert("RGB")).astype(int)
+        assert mine.shape == ref.shape
+        d = np.abs(mine - ref)
+        assert d.max() <= 3 and d.mean() <= 0.5, (name, d.max(), d.mean())
+    Image.fromarray(picture(32, 32)).save(str(tmp_path / "p.jpg"), progressive=True)
+    assert subprocess.call([cli, "--decode-image", str(tmp_path / "p.jpg"), str(tmp_path / "p.ppm")], stderr=subprocess.DEVNULL) == 1
+    # and through the scene loader: a JPEG map_Kd ends up as (c/255)^2.2 texels (MTL: one `newmtl` block per material, in order)
+    import json
+    s = pkg.scenes.bathroom_stress(32, 18, detail=4, tex_size=16)
+    obj = s.write(str(tmp_path))
+    mtl = obj[:-3] + "mtl"
+    lines = open(mtl).read().splitlines()
+    expected = 0.0; n_jpeg = 0
+    for i, l in enumerate(lines):
+        if l.startswith("map_Kd"):
+            src = os.path.join(str(tmp_path), l.split()[1]); jpg = os.path.splitext(src)[0] + ".jpg"
+            Image.open(src).convert("RGB").save(jpg, quality=95, subsampling=0)
+            lines[i] = "map_Kd " + os.path.basename(jpg); n_jpeg += 1
+            expected += float(pkg.texture_to_float(np.asarray(Image.open(jpg).convert("RGB"))).sum())
+    assert n_jpeg >= 1
+    open(mtl, "w").write("\n".join(lines) + "\n")
+    expected += sum(float(np.asarray(m.kd, np.float32).sum()) for m in s.materials if m.texture is None)
+    j = json.loads(subprocess.check_output([cli, obj, "--check"]).decode().strip().splitlines()[-1])
+    assert j["status"] == 0 and np.isclose(j["sum_tex"], expected, rtol=1e-2), (j["sum_tex"], expected)
