@@ -7,6 +7,7 @@
 #include "Model.h"
 #include "Jpeg.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,23 +21,28 @@ namespace {
 std::string dir_of(const std::string& p) { size_t k = p.find_last_of("/\\"); return k == std::string::npos ? std::string(".") : p.substr(0, k); }
 bool starts(const std::string& s, const char* t) { return s.compare(0, std::strlen(t), t) == 0; }
 
-// ---- minimal PNG (8-bit, colour types 0/2/6, non-interlaced) via zlib; returns RGB bytes
+// ---- PNG via zlib: every colour type (grey, RGB, palette, grey+alpha, RGBA), bit depths 1-16, non-interlaced; returns RGB bytes
+//      (16-bit samples keep their high byte, alpha is dropped -- what stb_image's 8-bit RGB request does)
 uint32_t be32(const unsigned char* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
 bool load_png(const std::vector<unsigned char>& f, int& w, int& h, std::vector<unsigned char>& rgb) {
     static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (f.size() < 33 || std::memcmp(f.data(), sig, 8) != 0) return false;
-    size_t pos = 8; int depth = 0, ctype = 0, interlace = 0; std::vector<unsigned char> idat;
+    size_t pos = 8; int depth = 0, ctype = 0, interlace = 0; std::vector<unsigned char> idat, plte;
     while (pos + 12 <= f.size()) {
         uint32_t len = be32(&f[pos]); const char* type = (const char*)&f[pos + 4];
-        if (pos + 12 + len > f.size()) return false;
-        if (!std::memcmp(type, "IHDR", 4)) { w = int(be32(&f[pos + 8])); h = int(be32(&f[pos + 12])); depth = f[pos + 16]; ctype = f[pos + 17]; interlace = f[pos + 20]; }
+        if (pos + 12 + size_t(len) > f.size()) return false;
+        if (!std::memcmp(type, "IHDR", 4) && len >= 13) { w = int(be32(&f[pos + 8])); h = int(be32(&f[pos + 12])); depth = f[pos + 16]; ctype = f[pos + 17]; interlace = f[pos + 20]; }
+        else if (!std::memcmp(type, "PLTE", 4)) plte.assign(f.begin() + pos + 8, f.begin() + pos + 8 + len);
         else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), f.begin() + pos + 8, f.begin() + pos + 8 + len);
         else if (!std::memcmp(type, "IEND", 4)) break;
-        pos += 12 + len;
+        pos += 12 + size_t(len);
     }
-    if (depth != 8 || interlace != 0 || (ctype != 0 && ctype != 2 && ctype != 6) || w <= 0 || h <= 0) return false;
-    const int ch = ctype == 0 ? 1 : (ctype == 2 ? 3 : 4);
-    const size_t stride = size_t(w) * ch;
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                          ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+    if (ch == 0 || !depth_ok || interlace != 0 || w <= 0 || h <= 0 || size_t(w) * size_t(h) > (size_t(1) << 28) || (ctype == 3 && plte.size() < 3)) return false;
+    const size_t bpp = std::max<size_t>(1, size_t(ch) * depth / 8);            // filter distance in bytes
+    const size_t stride = (size_t(w) * ch * depth + 7) / 8;
     std::vector<unsigned char> raw((stride + 1) * h);
     uLongf out = uLongf(raw.size());
     if (uncompress(raw.data(), &out, idat.data(), uLong(idat.size())) != Z_OK || out != raw.size()) return false;
@@ -45,7 +51,7 @@ bool load_png(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
         const unsigned char ft = raw[y * (stride + 1)]; const unsigned char* s = &raw[y * (stride + 1) + 1];
         unsigned char* d = &img[y * stride]; const unsigned char* up = y ? &img[(y - 1) * stride] : nullptr;
         for (size_t i = 0; i < stride; i++) {
-            int a = i >= size_t(ch) ? d[i - ch] : 0, b = up ? up[i] : 0, c = (up && i >= size_t(ch)) ? up[i - ch] : 0, v = s[i];
+            int a = i >= bpp ? d[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, v = s[i];
             switch (ft) {
                 case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
                 case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
@@ -55,8 +61,21 @@ bool load_png(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
         }
     }
     rgb.resize(size_t(w) * h * 3);
-    for (size_t i = 0; i < size_t(w) * h; i++)
-        for (int k = 0; k < 3; k++) rgb[3 * i + k] = img[i * ch + (ch == 1 ? 0 : k)];
+    const int maxv = (1 << (depth < 8 ? depth : 8)) - 1;
+    for (int y = 0; y < h; y++) {
+        const unsigned char* row = &img[size_t(y) * stride];
+        for (int x = 0; x < w; x++) {
+            unsigned char* o = &rgb[3 * (size_t(y) * w + x)];
+            auto sample = [&](int k) -> int {                                      // k-th channel of pixel x, 8 significant bits
+                if (depth == 16) return row[2 * (size_t(x) * ch + k)];
+                if (depth == 8) return row[size_t(x) * ch + k];
+                const size_t bit = size_t(x) * depth; return (row[bit >> 3] >> (8 - depth - int(bit & 7))) & maxv;
+            };
+            if (ctype == 3) { const size_t i = size_t(sample(0)); const unsigned char* p = 3 * i + 2 < plte.size() ? &plte[3 * i] : &plte[0]; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+            else if (ch <= 2) { int g = sample(0); if (depth < 8) g = g * 255 / maxv; o[0] = o[1] = o[2] = (unsigned char)g; }
+            else { o[0] = (unsigned char)sample(0); o[1] = (unsigned char)sample(1); o[2] = (unsigned char)sample(2); }
+        }
+    }
     return true;
 }
 bool load_ppm(const std::vector<unsigned char>& f, int& w, int& h, std::vector<unsigned char>& rgb) {
@@ -87,7 +106,7 @@ bool load_image_rgb8(const std::string& filename, int& w, int& h, std::vector<un
 Texture::Texture(const std::string& filename) {
     std::vector<unsigned char> rgb; int w = 0, h = 0;
     if (!load_image_rgb8(filename, w, h, rgb)) {
-        std::cerr << "Error: cannot decode texture (8-bit PNG, baseline JPEG or binary PPM expected): " << filename << std::endl;
+        std::cerr << "Error: cannot decode texture (non-interlaced PNG, baseline JPEG or binary PPM expected): " << filename << std::endl;
         ok = false; image_color.push_back(Color3f{0.5f, 0.5f, 0.5f}); return;
     }
     image_w = w; image_h = h;

@@ -236,3 +236,22 @@ def test_cpp_host_loader_decodes_jpeg_textures(pkg, tmp_path):
     expected += sum(float(np.asarray(m.kd, np.float32).sum()) for m in s.materials if m.texture is None)
     j = json.loads(subprocess.check_output([cli, obj, "--check"]).decode().strip().splitlines()[-1])
     assert j["status"] == 0 and np.isclose(j["sum_tex"], expected, rtol=1e-2), (j["sum_tex"], expected)
+
+
+def test_cpp_host_loader_decodes_every_png_flavour(pkg, tmp_path):
+    """PNG colour types 0/2/3/4/6, bit depths 1-16 (host/Model.cpp, zlib inflate + own unfiltering) -- exact against Pillow."""
+    Image = pytest.importorskip("PIL.Image")
+    cli = os.path.join(ROOT, "monte-carlo-path-tracer_amd", "csrc", "mcpt_cli")
+    rng = np.random.RandomState(5)
+    a = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    cases = {"rgb": Image.fromarray(a), "rgba": Image.fromarray(np.dstack([a, rng.randint(0, 256, (37, 53, 1)).astype(np.uint8)])),
+             "grey": Image.fromarray(a[..., 0]), "la": Image.fromarray(np.dstack([a[..., 0], a[..., 1]]), "LA"), "pal": Image.fromarray(a).quantize(200),
+             "pal4": Image.fromarray(a).quantize(13), "bw": Image.fromarray(a[..., 0] > 128), "g16": Image.fromarray(a[..., 0].astype(np.uint16) * 257)}
+    for k, im in cases.items():
+        src = str(tmp_path / (k + ".png")); out = str(tmp_path / (k + ".ppm"))
+        im.save(src)
+        subprocess.check_call([cli, "--decode-image", src, out])
+        d = open(out, "rb").read(); parts = d.split(b"\n", 3); w, h = map(int, parts[1].split())
+        mine = np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
+        want = np.repeat(a[..., :1], 3, axis=2) if k == "g16" else np.asarray(Image.open(src).convert("RGB"))   # 16-bit: high byte
+        assert np.array_equal(mine, want), k
