@@ -12,8 +12,12 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <future>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -55,7 +59,13 @@ public:
             max_leaf = uint32_t(n); depth = 1;
             return;
         }
+        // Subtrees are independent (disjoint ranges of order_, node records claimed from an atomic counter), so the top levels of
+        // a large scene fork one task per child.  The topology does not depend on the schedule; node NUMBERS do, and the caller
+        // renumbers breadth-first anyway.
+        nodes_.resize(4 * size_t(n));                                  // upper bound: n - 1 inner nodes
         build(0, n, 0, rb);
+        nodes_.resize(4 * size_t(next_node_.load()));
+        depth = depth_.load(); max_leaf = max_leaf_.load();
     }
     const std::vector<int>& order() const { return order_; }
     uint32_t depth = 0, max_leaf = 0;
@@ -84,10 +94,10 @@ private:
         const int n = r - l;
         for (int i = l; i < r; i++) box.grow(t_[order_[i]].lo, t_[order_[i]].hi);
         if (n <= MCPT_LEAF_MAX) {
-            max_leaf = std::max(max_leaf, uint32_t(n));
+            atomic_max(max_leaf_, uint32_t(n));
             return leaf_code(uint32_t(l), uint32_t(n));
         }
-        depth = std::max(depth, uint32_t(d + 1));
+        atomic_max(depth_, uint32_t(d + 1));
         Box cb;
         for (int i = l; i < r; i++) cb.grow_pt(t_[order_[i]].c);
         int mid = -1;
@@ -132,14 +142,24 @@ private:
             std::nth_element(order_.begin() + l, order_.begin() + mid, order_.begin() + r,
                              [&](int x, int y) { return t_[x].c[a] < t_[y].c[a]; });
         }
-        const int idx = int(nodes_.size() / 4);
-        nodes_.resize(nodes_.size() + 4);
+        const int idx = next_node_.fetch_add(1);
         Box b0, b1;
-        const int c0 = build(l, mid, d + 1, b0);
-        const int c1 = build(mid, r, d + 1, b1);
+        int c0, c1;
+        if (n >= kForkMin && d < kForkDepth) {
+            auto left = std::async(std::launch::async, [&]() { return build(l, mid, d + 1, b0); });
+            c1 = build(mid, r, d + 1, b1);
+            c0 = left.get();
+        } else {
+            c0 = build(l, mid, d + 1, b0);
+            c1 = build(mid, r, d + 1, b1);
+        }
         write_node(idx, b0, c0, b1, c1);
         return idx;
     }
+    static void atomic_max(std::atomic<uint32_t>& a, uint32_t v) { uint32_t cur = a.load(); while (cur < v && !a.compare_exchange_weak(cur, v)) {} }
+    static constexpr int kForkMin = 1 << 15, kForkDepth = 5;          // fork while a range has >= 32 k triangles, at most 32 tasks
+    std::atomic<int> next_node_{0};
+    std::atomic<uint32_t> depth_{0}, max_leaf_{0};
 
     const std::vector<BTri>& t_;
     std::vector<f4h>& nodes_;
@@ -343,6 +363,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     } else {
         Builder b(bt, out.nodes);
         b.run();
+        if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] SAH %.0f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         out.bvh_depth = b.depth; out.max_leaf = b.max_leaf;
         order = b.order();
     }
