@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace {
 
@@ -165,6 +166,15 @@ private:
     std::vector<f4h>& nodes_;
     std::vector<int> order_;
 };
+
+// static chunking over hardware threads for the embarrassingly parallel per-triangle loops of large scenes
+template <class F> void parallel_for(uint32_t n, F&& body) {
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency()), nt = n < (1u << 16) ? 1u : std::min(hw, 16u);
+    if (nt == 1) { body(0u, n); return; }
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nt; t++) th.emplace_back([&, t]() { body(uint32_t(uint64_t(n) * t / nt), uint32_t(uint64_t(n) * (t + 1) / nt)); });
+    for (auto& x : th) x.join();
+}
 
 inline double len3(const double* v) { return std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
 
@@ -404,7 +414,8 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
 
     // ---- streams in leaf order
     out.tri_isect.resize(3 * size_t(nf)); out.tri_shade.resize(4 * size_t(nf)); out.tri_pos64.resize(9 * size_t(nf)); out.tri_plane64.resize(4 * size_t(nf)); out.tri_face.resize(nf);
-    for (uint32_t i = 0; i < nf; i++) {
+    parallel_for(nf, [&](uint32_t i_begin, uint32_t i_end) {
+    for (uint32_t i = i_begin; i < i_end; i++) {
         const int f = order[i];
         const int32_t* c = d->face + 12 * size_t(f);
         const double* v0 = d->vertex + 3 * c[0]; const double* v1 = d->vertex + 3 * c[4]; const double* v2 = d->vertex + 3 * c[8];
@@ -426,6 +437,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         }
         out.tri_face[i] = f;
     }
+    });
 
     // ---- lights in face order (Render.cpp:41-42)
     out.lights.clear();
