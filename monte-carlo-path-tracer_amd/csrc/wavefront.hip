@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     else if (state == SLOT_DRAIN) terminated = true;
 #endif
 
-    if (terminated || (state == SLOT_DEAD && id.z == id.w)) { sm = ld_s(&pool.sum[slot]); sm_loaded = true; }
+    // one-sample items (the default) flush every finished sample straight to the film: their accumulator record is always zero, so
+    // it is neither fetched (a dependent round trip in front of the regeneration) nor written back
+    if (p.samples_per_item != 1u && (terminated || (state == SLOT_DEAD && id.z == id.w))) { sm = ld_s(&pool.sum[slot]); sm_loaded = true; }
     if (terminated) {                                                                           // Scene::set_Pixel, per sample
         const f3 c = wf_scrub_nan(L);
         sm.x += c.x; sm.y += c.y; sm.z += c.z; sm.w += 1.f; sum_dirty = true;
