@@ -26,7 +26,9 @@
 #ifndef MCPT_STACK_DEPTH
 #define MCPT_STACK_DEPTH 64        // LDS traversal stack entries per lane of the binary-tree kernels (host SAH trees: depth <= 30; device LBVH trees: <= 63, checked)
 #endif
+#ifndef MCPT_BLOCK
 #define MCPT_BLOCK 256             // threads per workgroup = 4 waves of 64
+#endif
 #ifndef MCPT_TOP_NODES
 #define MCPT_TOP_NODES 256         // nodes numbered breadth-first by the builder; the trace kernel serves them from LDS
 #endif

@@ -75,10 +75,10 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     __shared__ float4 s_lights[WF_LDS_LIGHTS * 4];
     __shared__ double s_light_pos[WF_LDS_LIGHTS * 9];
     const bool mats_lds = sc.n_mats <= WF_LDS_MATS, lights_lds = sc.n_lights <= WF_LDS_LIGHTS;
-    if (mats_lds && threadIdx.x < (uint32_t)sc.n_mats * 4) s_mats[threadIdx.x] = reinterpret_cast<const float4*>(sc.mats)[threadIdx.x];
+    if (mats_lds) for (uint32_t i = threadIdx.x; i < (uint32_t)sc.n_mats * 4; i += MCPT_BLOCK) s_mats[i] = reinterpret_cast<const float4*>(sc.mats)[i];
     if (lights_lds) {
-        if (threadIdx.x < (uint32_t)sc.n_lights * 4) s_lights[threadIdx.x] = reinterpret_cast<const float4*>(sc.lights)[threadIdx.x];
-        if (threadIdx.x < (uint32_t)sc.n_lights * 9) s_light_pos[threadIdx.x] = sc.tri_pos64[9 * (size_t)sc.lights[threadIdx.x / 9].tri + threadIdx.x % 9];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.n_lights * 4; i += MCPT_BLOCK) s_lights[i] = reinterpret_cast<const float4*>(sc.lights)[i];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.n_lights * 9; i += MCPT_BLOCK) s_light_pos[i] = sc.tri_pos64[9 * (size_t)sc.lights[i / 9].tri + i % 9];
     }
     __syncthreads();
 
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         if (lane == 0) s_wave_cnt[wv_] = (uint32_t)__popcll(m);
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+            uint32_t tot = 0; for (uint32_t k = 0; k < MCPT_BLOCK / 64; k++) tot += s_wave_cnt[k];
             uint32_t base = 0xffffffffu, sel = 0;
             if (tot) {
                 for (uint32_t probe = 0; probe < 4; probe++) {
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     const uint64_t ms = __ballot(emit_shadow);
     if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(ms);
     __syncthreads();
-    if (threadIdx.x == 0) st_s(&pool.shadow_count[blockIdx.x], s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3]);
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (uint32_t k = 0; k < MCPT_BLOCK / 64; k++) tot += s_wave_cnt[k]; st_s(&pool.shadow_count[blockIdx.x], tot); }
     if (emit_shadow) {
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
