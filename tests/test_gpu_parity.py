@@ -373,3 +373,22 @@ def test_frame_by_frame_equals_one_call(pkg):
         r.render(1, seed=3, first_sample=f)
     a = r.read_accum(); r.clear(); r.render(6, seed=3); b = r.read_accum(); r.close()
     assert np.array_equal(a[..., 3], b[..., 3]) and np.allclose(a, b, rtol=2e-5, atol=1e-5)
+
+
+def test_two_triangle_scene_and_explicit_item_sizes(pkg, orc):
+    """Smallest scene the builders accept (one light quad = a single leaf under an artificial root), with and without the device
+    BVH flag (which falls back to the host path for <= 2 triangles), and explicit samples_per_item values around the automatic one."""
+    base = pkg.scenes.open_box(24, 24)
+    light = pkg.scenes.SceneData("light-only", base.vertex, base.normal, base.texcoord, base.face[-2:], base.materials, base.camera)
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    cpu, _, _ = orc.Oracle(light, max_depth=3, flags=flags).render(8, seed=2)
+    for fl in (flags, flags | pkg.FLAG_GPU_BVH_BUILD):
+        r = pkg.Renderer(light, max_depth=3, flags=fl); r.render(8, seed=2); g = r.read_accum(); r.close()
+        assert np.all(g[..., 3] == 8) and _frac_beyond(g[..., :3] / 8, cpu[..., :3] / 8) <= 0.01
+    scene = pkg.scenes.cornell_box_small(40, 24)
+    ref = None
+    for spi in (0, 1, 3, 8, 64):
+        r = pkg.Renderer(scene, max_depth=4, flags=flags, samples_per_item=spi); r.render(24, seed=5); g = r.read_accum(); r.close()
+        assert np.all(g[..., 3] == 24)
+        if ref is None: ref = g
+        else: assert np.allclose(g, ref, rtol=1e-4, atol=1e-4), spi        # same samples, different summation order
