@@ -13,7 +13,7 @@
 //                    __ballot/__popcll: it runs the inner-node block while most lanes sit at inner nodes, the leaf block
 //                    once enough lanes wait at a leaf, and the refill block (write results back, pull fresh rays from a
 //                    wave-private chunk of the list) once enough lanes are idle -- so the expensive blocks execute with
-//                    well-packed lanes.  64 VGPRs; 1024-thread blocks with 64 KB of LDS (top tree levels + per-lane stack).
+//                    well-packed lanes.  69 VGPRs; 1024-thread blocks with 64 KB of LDS (top tree levels + per-lane stack).
 // DESIGN.md §5 has the measurements behind each of these choices.
 #include "pt_device.h"
 #include "wavefront.h"
@@ -371,10 +371,16 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
     uint32_t w_next = 0, w_end = 0, q_base = 0;      // current chunk: item range [w_next, w_end); shadow chunks: queue offset q_base
     bool chunk_shadow = false, exhausted = false;
-    auto take_chunk = [&](uint32_t c) {
-        if (c >= n_chunks) { exhausted = true; w_next = w_end = 0; return; }
-        if (c < n_ext_chunks) { chunk_shadow = false; w_next = c * MCPT_BLOCK; w_end = w_next + MCPT_BLOCK; }
-        else { chunk_shadow = true; const uint32_t b = c - n_ext_chunks; q_base = b * MCPT_BLOCK; w_next = 0; w_end = wave_first(ld_s(&pool.shadow_count[b])); }
+    auto take_chunk = [&](uint32_t c) {              // (straight-line on purpose: with early returns the compiler kept w_next / w_end in scratch)
+        const bool none = c >= n_chunks, ext = c < n_ext_chunks, shadow = !none && !ext;
+        const uint32_t b = shadow ? c - n_ext_chunks : 0u;
+        uint32_t cnt = 0;
+        if (shadow) cnt = wave_first(ld_s(&pool.shadow_count[b]));
+        exhausted = exhausted || none;
+        chunk_shadow = shadow;
+        q_base = b * MCPT_BLOCK;
+        w_next = ext ? c * MCPT_BLOCK : 0u;
+        w_end = ext ? c * MCPT_BLOCK + MCPT_BLOCK : cnt;
     };
     // chunks are reserved WF_CHUNK_BATCH at a time: one atomic on `head` per ~1-2 k rays per wave
     uint32_t c_next = (blockIdx.x * (WF_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) * WF_CHUNK_BATCH, c_end = c_next + WF_CHUNK_BATCH;
