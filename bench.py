@@ -111,7 +111,8 @@ def main():
     stream = torch.cuda.current_stream(dev)
     r.set_stream(stream.cuda_stream)
 
-    def step(s):
+    def step(s):                            # one step = one complete render job: clear the film, render this rank's sample range, sum the films
+        accum.zero_()
         r.render(args.spp, seed=20251004, first_sample=mg.first_sample(s, rank, world, args.spp))
         mg.all_reduce_film(accum)           # RCCL sum over xGMI on the same stream (no-op for one rank)
 
@@ -121,10 +122,9 @@ def main():
         torch.cuda.synchronize(dev)
 
     for s in range(args.warmup):
-        accum.zero_(); step(s)
+        step(s)
     fence()
     r.reset_counters()
-    accum.zero_()
     fence()
     t0 = time.perf_counter()
     for s in range(args.steps):
