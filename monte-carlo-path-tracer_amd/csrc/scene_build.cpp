@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <system_error>
 #include <thread>
 
 namespace {
@@ -146,8 +147,12 @@ private:
         const int idx = next_node_.fetch_add(1);
         Box b0, b1;
         int c0, c1;
+        std::future<int> left;
         if (n >= kForkMin && d < kForkDepth) {
-            auto left = std::async(std::launch::async, [&]() { return build(l, mid, d + 1, b0); });
+            try { left = std::async(std::launch::async, [&]() { return build(l, mid, d + 1, b0); }); }
+            catch (const std::system_error&) {}                        // no thread to be had: build both children here
+        }
+        if (left.valid()) {
             c1 = build(mid, r, d + 1, b1);
             c0 = left.get();
         } else {
