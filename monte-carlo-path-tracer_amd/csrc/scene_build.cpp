@@ -177,7 +177,11 @@ template <class F> void parallel_for(uint32_t n, F&& body) {
     const uint32_t hw = std::max(1u, std::thread::hardware_concurrency()), nt = n < (1u << 16) ? 1u : std::min(hw, 16u);
     if (nt == 1) { body(0u, n); return; }
     std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nt; t++) th.emplace_back([&, t]() { body(uint32_t(uint64_t(n) * t / nt), uint32_t(uint64_t(n) * (t + 1) / nt)); });
+    for (uint32_t t = 0; t < nt; t++) {
+        const uint32_t b = uint32_t(uint64_t(n) * t / nt), e = uint32_t(uint64_t(n) * (t + 1) / nt);
+        try { th.emplace_back([&body, b, e]() { body(b, e); }); }
+        catch (const std::system_error&) { body(b, e); }              // no thread to be had: do this chunk here
+    }
     for (auto& x : th) x.join();
 }
 
