@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MCPT_ABI_VERSION 1
+#define MCPT_ABI_VERSION 2
 
 typedef enum mcpt_status {
     MCPT_OK = 0,
@@ -111,6 +111,7 @@ typedef struct mcpt_counters {
     double   trace_ms_total;    /* wavefront pipeline, detailed timing on: summed duration of the traversal kernel ... */
     double   shade_ms_total;    /* ... and of the shade kernel since the last reset (0 when detailed timing is off) */
     uint64_t iterations;        /* [shade, trace] iterations since the last reset (each is one launch of either kernel) */
+    uint64_t stack_spills;      /* traversal-stack entries that left LDS for the global overflow area (only with COUNT_TRAVERSAL) */
 } mcpt_counters;
 
 typedef struct mcpt_scene_info {
@@ -162,8 +163,11 @@ mcpt_status mcpt_reset_counters(mcpt_ctx* ctx);
  * torch.distributed / RCCL all-reduces in place).  NULL re-binds the internal buffer. */
 mcpt_status mcpt_bind_accum(mcpt_ctx* ctx, void* device_rgba);
 mcpt_status mcpt_accum_device_ptr(mcpt_ctx* ctx, void** out_device_rgba);
-/* Launch on a caller-owned hipStream_t (NULL = the context's own stream). */
+/* Launch on a caller-owned hipStream_t.  NULL = back to the context's own (non-blocking) stream -- NOT the device's legacy
+ * default stream, whose handle is also 0: a caller that wants its work ordered with the default stream (e.g. torch's
+ * default stream, `cuda_stream == 0`) says so with mcpt_set_null_stream(). */
 mcpt_status mcpt_set_stream(mcpt_ctx* ctx, void* hip_stream);
+mcpt_status mcpt_set_null_stream(mcpt_ctx* ctx);
 
 /* ---- function-level probes (what the parity tests call; each maps to one reference function) ---------- */
 /* BVH::hit (BVH.cpp:90-113) / BVH::has_hit (BVH.cpp:115-136) for n host rays.  origin/dir: 3 doubles per ray.
@@ -172,6 +176,13 @@ mcpt_status mcpt_set_stream(mcpt_ctx* ctx, void* hip_stream);
 mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir,
                              const double* t1, const double* t2, int any_hit,
                              float* out_t, int32_t* out_tri, float* out_u, float* out_v);
+/* The same two reference functions through the PRODUCTION traversal kernel (wf_trace_kernel over the 4-wide quantised tree:
+ * LDS top levels, LDS + global overflow stack, chunked ray list): the rays are placed in a path pool the way the shade kernel
+ * leaves them, the trace kernel runs once, results come back from the pool.  t1 is the kernel's fixed 1e-4 (Render.h:30);
+ * closest-hit rays are unbounded (t2 = DBL_MAX like cast_Ray / BSDF rays), any-hit rays use t2[i] (Render.cpp:219-221).
+ * Same outputs as mcpt_probe_trace. */
+mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, const double* t2, int any_hit,
+                              float* out_t, int32_t* out_tri, float* out_u, float* out_v);
 /* Render::cast_Ray (Render.cpp:71-80) for n (x,y) pixels with the xi the caller supplies (2 per ray). */
 mcpt_status mcpt_probe_cast_ray(mcpt_ctx* ctx, uint32_t n, const int32_t* xy, const float* xi, float* out_origin_dir6);
 /* BSDF (BSDF.cpp:87-202) on synthetic hits: per item normal[3], wi[3], kd[3], ks[3], ns, wo[3] (world) and 3 xi
@@ -183,7 +194,8 @@ mcpt_status mcpt_probe_bsdf(mcpt_ctx* ctx, uint32_t n, const float* normal, cons
  * of SURVEY A-9 evaluated on the sampled triangle only) = 10 floats */
 mcpt_status mcpt_probe_sample_light(mcpt_ctx* ctx, uint32_t n, const double* point, const float* xi, float* out10);
 /* One full path per item through the shipping integrator from a given ray, random numbers from the counter-based
- * generator keyed (seed, pixel = item, sample = 0).  out: L[3]. */
+ * generator keyed (seed, pixel = item, sample = 0).  out: L[3].  Runs the production wavefront pipeline (wf_shade_kernel +
+ * wf_trace_kernel over a path pool, item = entry of an n x 1 film); the cross-check megakernel only under MCPT_PIPELINE=mega. */
 mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, uint64_t seed, float* out_L3);
 /* The generator itself: n*4 uniforms for (pixel, sample, block) triples -- pins oracle and device to one stream. */
 mcpt_status mcpt_probe_rng(mcpt_ctx* ctx, uint32_t n, const uint32_t* pixel_sample_block3, uint64_t seed, float* out4);

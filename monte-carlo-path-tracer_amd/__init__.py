@@ -66,7 +66,8 @@ class Counters(C.Structure):
                 ("shaded_hits", C.c_uint64), ("texel_fetches", C.c_uint64),
                 ("self_shadow_tests", C.c_uint64), ("self_shadow_hits", C.c_uint64),
                 ("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("launches", C.c_uint64),
-                ("trace_ms_total", C.c_double), ("shade_ms_total", C.c_double), ("iterations", C.c_uint64)]
+                ("trace_ms_total", C.c_double), ("shade_ms_total", C.c_double), ("iterations", C.c_uint64),
+                ("stack_spills", C.c_uint64)]
 
     @property
     def rays(self) -> int:
@@ -165,6 +166,8 @@ def load_library() -> C.CDLL:
         "mcpt_bind_accum": [vp, vp],
         "mcpt_accum_device_ptr": [vp, P(vp)],
         "mcpt_set_stream": [vp, vp],
+        "mcpt_set_null_stream": [vp],
+        "mcpt_probe_trace4": [vp, C.c_uint32, vp, vp, vp, C.c_int, vp, vp, vp, vp],
         "mcpt_probe_trace": [vp, C.c_uint32, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp],
         "mcpt_probe_cast_ray": [vp, C.c_uint32, vp, vp, vp],
         "mcpt_probe_bsdf": [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -186,7 +189,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_create", "mcpt_destroy", "mcpt_check_scene", "mcpt_get_scene_info", "mcpt_last_error", "mcpt_abi_version",
     "mcpt_render", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap",
     "mcpt_get_counters", "mcpt_reset_counters", "mcpt_bind_accum", "mcpt_accum_device_ptr", "mcpt_set_stream",
-    "mcpt_probe_trace", "mcpt_probe_cast_ray", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
+    "mcpt_set_null_stream", "mcpt_probe_trace", "mcpt_probe_trace4", "mcpt_probe_cast_ray", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
     "mcpt_probe_paths", "mcpt_probe_rng",
 ]
 
@@ -279,7 +282,20 @@ class Renderer:
         self._check(self.lib.mcpt_bind_accum(self.ctx, C.c_void_p(device_ptr)))
 
     def set_stream(self, hip_stream: int):
+        """A caller-owned stream handle; 0 = back to the context's own stream (see set_null_stream for the default stream)."""
         self._check(self.lib.mcpt_set_stream(self.ctx, C.c_void_p(hip_stream)))
+
+    def set_null_stream(self):
+        """Order the context's work with the device's legacy default stream (torch's default stream has handle 0)."""
+        self._check(self.lib.mcpt_set_null_stream(self.ctx))
+
+    def set_torch_stream(self, stream):
+        """Bind a torch.cuda.Stream: its handle, or the legacy default stream when the handle is 0."""
+        h = int(stream.cuda_stream)
+        if h:
+            self.set_stream(h)
+        else:
+            self.set_null_stream()
 
     # ---- probes
     def probe_trace(self, origin, direction, t1=None, t2=None, any_hit=False):
@@ -290,6 +306,16 @@ class Renderer:
         ot = np.zeros(n, np.float32); tri = np.zeros(n, np.int32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
         self._check(self.lib.mcpt_probe_trace(self.ctx, n, _ptr(o), _ptr(d), _ptr(t1), _ptr(t2), 1 if any_hit else 0,
                                               _ptr(ot), _ptr(tri), _ptr(u), _ptr(v)))
+        return ot, tri, u, v
+
+    def probe_trace4(self, origin, direction, t2=None, any_hit=False):
+        """BVH::hit / has_hit through the production wf_trace_kernel (4-wide quantised tree)."""
+        o = np.ascontiguousarray(origin, np.float64).reshape(-1, 3); d = np.ascontiguousarray(direction, np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        t2 = np.full(n, np.finfo(np.float64).max) if t2 is None else np.ascontiguousarray(t2, np.float64)
+        ot = np.zeros(n, np.float32); tri = np.zeros(n, np.int32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        self._check(self.lib.mcpt_probe_trace4(self.ctx, n, _ptr(o), _ptr(d), _ptr(t2), 1 if any_hit else 0,
+                                               _ptr(ot), _ptr(tri), _ptr(u), _ptr(v)))
         return ot, tri, u, v
 
     def probe_cast_ray(self, xy, xi):

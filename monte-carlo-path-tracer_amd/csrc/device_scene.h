@@ -93,9 +93,12 @@ struct RenderParams {
     uint32_t integrator;
     uint32_t seed_lo, seed_hi;
     uint32_t atomic_accum;         // 1: several items per pixel -> float atomics; 0: plain read-modify-write
+    uint32_t probe_n;              // mcpt_probe_paths through the wavefront pipeline: item i (< probe_n) = "pixel" i of an n x 1 film,
+    const double* probe_o;         //   whose one sample starts from the caller's ray (probe_o/probe_d: 3 doubles each) instead of
+    const double* probe_d;         //   cast_Ray.  All three are 0 in a render.
 };
 
 struct DevCounters {               // mirrors the integer part of mcpt_counters
     unsigned long long paths, rays_primary, rays_continuation, rays_shadow, box_tests, tri_tests, shaded_hits,
-        texel_fetches, self_shadow_tests, self_shadow_hits;
+        texel_fetches, self_shadow_tests, self_shadow_hits, stack_spills;
 };

@@ -62,6 +62,7 @@ struct mcpt_ctx {
     uint32_t time_kernels = 0;          // MCPT_TIME_KERNELS=N: bracket the two kernels of every Nth iteration with HIP events (0 = off)
     double last_trace_ms = 0.0, total_trace_ms = 0.0, last_shade_ms = 0.0, total_shade_ms = 0.0;
     uint64_t total_iterations = 0;
+    std::vector<int32_t> h_tri_face;      // leaf order -> face index, fetched on first use by mcpt_probe_trace4
 };
 
 namespace {
@@ -323,11 +324,11 @@ static mcpt_status resolve_timing(mcpt_ctx* c) {
     return MCPT_OK;
 }
 
-static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
+static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* accum) {
     // One mcpt_render call = per sub-pipeline a loop of [shade, trace] launches over its slot pool until its work items are done.
     // The sample range is split contiguously over the sub-pipelines; their streams fork from and join the context's stream.
     const uint64_t tiles = uint64_t(p0.tiles_x) * p0.tiles_y;
-    const uint32_t n_lanes = uint32_t(ctx->lanes.size());
+    const uint32_t n_lanes = p0.probe_n ? 1u : uint32_t(ctx->lanes.size());    // a probe (mcpt_probe_paths) runs on one sub-pipeline
     const bool count = (p0.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
     const uint32_t CHECK = 4, RING = 8;
     const bool debug = env_u32("MCPT_WF_DEBUG", 0) != 0;
@@ -343,7 +344,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
         r.p = p0; r.p.spp = hi - lo; r.p.first_sample = p0.first_sample + lo;
         if (r.p.samples_per_item > r.p.spp) r.p.samples_per_item = r.p.spp;
         r.p.chunks = (r.p.spp + r.p.samples_per_item - 1) / r.p.samples_per_item;
-        r.n_items = uint32_t(tiles * 64 * r.p.chunks);
+        r.n_items = p0.probe_n ? p0.probe_n : uint32_t(tiles * 64 * r.p.chunks);
         r.pool = ctx->lanes[k].pool;
         const uint32_t want = uint32_t(((uint64_t(r.n_items) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
         if (r.pool.P > want) r.pool.P = want;                              // small jobs: do not sweep idle slots
@@ -397,7 +398,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0) {
             IterCtl* ctl = static_cast<IterCtl*>(L.ctl_buf.p);
             const bool timed = ctx->time_kernels && r.it % ctx->time_kernels == 0;
             HIP_TRY(k_event(L, r, timed));
-            HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_items, ctx->accum, cnt, L.stream));
+            HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_items, accum, cnt, L.stream));
             HIP_TRY(k_event(L, r, timed));
             HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(L.ovf_buf.p), L.stream));
             HIP_TRY(k_event(L, r, timed));
@@ -462,7 +463,7 @@ mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t fir
     if (tiles * p.chunks > 0x3ffffffull) return fail(MCPT_ERR_UNSUPPORTED, "launch too large: lower spp per call or raise samples_per_item");
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (ctx->use_wavefront) {
-        st = render_wavefront(ctx, p); if (st != MCPT_OK) return st;
+        st = render_wavefront(ctx, p, ctx->accum); if (st != MCPT_OK) return st;
     } else {
         HIP_TRY(launch_render(ctx->dev, p, ctx->accum, static_cast<DevCounters*>(ctx->counters.p), ctx->stream));
     }
@@ -520,12 +521,12 @@ mcpt_status mcpt_get_counters(mcpt_ctx* ctx, mcpt_counters* out) {
     for (const DevCounters& r : rep) {
         d.paths += r.paths; d.rays_primary += r.rays_primary; d.rays_continuation += r.rays_continuation; d.rays_shadow += r.rays_shadow;
         d.box_tests += r.box_tests; d.tri_tests += r.tri_tests; d.shaded_hits += r.shaded_hits; d.texel_fetches += r.texel_fetches;
-        d.self_shadow_tests += r.self_shadow_tests; d.self_shadow_hits += r.self_shadow_hits;
+        d.self_shadow_tests += r.self_shadow_tests; d.self_shadow_hits += r.self_shadow_hits; d.stack_spills += r.stack_spills;
     }
     std::memset(out, 0, sizeof *out);
     out->paths = d.paths; out->rays_primary = d.rays_primary; out->rays_continuation = d.rays_continuation; out->rays_shadow = d.rays_shadow;
     out->box_tests = d.box_tests; out->tri_tests = d.tri_tests; out->shaded_hits = d.shaded_hits; out->texel_fetches = d.texel_fetches;
-    out->self_shadow_tests = d.self_shadow_tests; out->self_shadow_hits = d.self_shadow_hits;
+    out->self_shadow_tests = d.self_shadow_tests; out->self_shadow_hits = d.self_shadow_hits; out->stack_spills = d.stack_spills;
     out->kernel_ms = ctx->last_kernel_ms; out->kernel_ms_total = ctx->total_kernel_ms; out->launches = ctx->launches;
     out->trace_ms_total = ctx->total_trace_ms; out->shade_ms_total = ctx->total_shade_ms; out->iterations = ctx->total_iterations;
     return MCPT_OK;
@@ -558,6 +559,14 @@ mcpt_status mcpt_set_stream(mcpt_ctx* ctx, void* hip_stream) {
     return MCPT_OK;
 }
 
+mcpt_status mcpt_set_null_stream(mcpt_ctx* ctx) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    st = resolve_timing(ctx); if (st != MCPT_OK) return st;
+    ctx->stream = nullptr;                                             // the device's legacy default stream
+    return MCPT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ probes
 mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, const double* t1, const double* t2, int any_hit,
                              float* out_t, int32_t* out_tri, float* out_u, float* out_v) {
@@ -571,6 +580,65 @@ mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, co
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(out_tri, d_tri, n * sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_u, d_u, n * sizeof(float), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(out_v, d_v, n * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+// The PRODUCTION traversal: the caller's rays are written into a path pool exactly as wf_shade_kernel would leave them (extend rays
+// in ray_o / ray_d, shadow rays in sh_d + the per-block shadow queue), wf_trace_kernel runs once over that pool, and the results
+// are read back from where wf_shade_kernel would pick them up (pool.hit; for shadow rays the L += nee the unoccluded ones perform).
+mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, const double* t2, int any_hit,
+                              float* out_t, int32_t* out_tri, float* out_u, float* out_v) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!origin || !dir || !out_t || !out_tri || !out_u || !out_v || (any_hit && !t2)) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (!ctx->use_wavefront || ctx->lanes.empty()) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_trace4 needs the wavefront pipeline (MIS integrator)");
+    if (n == 0) return MCPT_OK;
+    mcpt_ctx::WfLane& L = ctx->lanes[0];
+    PathPool pool = L.pool;
+    const uint32_t P = uint32_t(((uint64_t(n) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
+    if (P > pool.P) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_trace4: more rays than pool slots");
+    pool.P = P;
+    std::vector<float> ro(4 * size_t(P), 0.f), rd(4 * size_t(P), 0.f), sd(4 * size_t(P), 0.f), nee(4 * size_t(P), 0.f), hit(4 * size_t(P), 0.f);
+    std::vector<uint32_t> queue(P, 0u), qcount(P / MCPT_BLOCK, 0u);
+    const int32_t no_skip = -1; float no_skip_f; std::memcpy(&no_skip_f, &no_skip, 4);
+    for (uint32_t i = 0; i < P; i++) {
+        float* o4 = &ro[4 * size_t(i)]; float* d4 = &rd[4 * size_t(i)]; float* s4 = &sd[4 * size_t(i)];
+        o4[3] = no_skip_f; d4[2] = 1.f; s4[2] = 1.f;
+        if (i >= n) continue;
+        for (int k = 0; k < 3; k++) { o4[k] = float(origin[3 * size_t(i) + k]); d4[k] = float(dir[3 * size_t(i) + k]); s4[k] = d4[k]; }
+        if (any_hit) {
+            s4[3] = t2[i] > 3.0e38 ? 3.0e38f : float(t2[i]);
+            nee[4 * size_t(i)] = 1.f;                                   // unoccluded => L.x becomes 1
+            queue[i] = i;                                               // shade block b queues its own slots in order
+            qcount[i / MCPT_BLOCK]++;
+        } else d4[3] = 1.f;                                             // "an extend ray is pending"
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(pool.ray_o, ro.data(), ro.size() * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(pool.ray_d, rd.data(), rd.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pool.sh_d, sd.data(), sd.size() * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(pool.nee, nee.data(), nee.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(pool.L, 0, size_t(P) * 16)); HIP_TRY(hipMemset(pool.hit, 0xff, size_t(P) * 16));
+    HIP_TRY(hipMemcpy(pool.shadow_queue, queue.data(), queue.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pool.shadow_count, qcount.data(), qcount.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(L.ctl_buf.p, 0, sizeof(IterCtl)));
+    const bool count = (ctx->opts.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
+    HIP_TRY(launch_wf_trace(ctx->dev, pool, static_cast<IterCtl*>(L.ctl_buf.p), 0u, ctx->tune, count, static_cast<DevCounters*>(ctx->counters.p), ctx->trace_grid,
+                            static_cast<int*>(L.ovf_buf.p), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (any_hit) {
+        HIP_TRY(hipMemcpy(hit.data(), pool.L, hit.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) { out_tri[i] = hit[4 * size_t(i)] == 1.f ? 0 : 1; out_t[i] = 0.f; out_u[i] = 0.f; out_v[i] = 0.f; }
+    } else {
+        if (ctx->h_tri_face.empty()) {
+            ctx->h_tri_face.resize(size_t(ctx->dev.n_tris));
+            HIP_TRY(hipMemcpy(ctx->h_tri_face.data(), ctx->dev.tri_face, ctx->h_tri_face.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        HIP_TRY(hipMemcpy(hit.data(), pool.hit, hit.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) {
+            int32_t tri; std::memcpy(&tri, &hit[4 * size_t(i)], 4);
+            if (tri >= ctx->dev.n_tris) return fail(MCPT_ERR_HIP, "mcpt_probe_trace4: trace kernel returned an out-of-range triangle");
+            out_tri[i] = tri < 0 ? -1 : ctx->h_tri_face[size_t(tri)];
+            out_u[i] = tri < 0 ? 0.f : hit[4 * size_t(i) + 1]; out_v[i] = tri < 0 ? 0.f : hit[4 * size_t(i) + 2]; out_t[i] = tri < 0 ? 0.f : hit[4 * size_t(i) + 3];
+        }
+    }
     return MCPT_OK;
 }
 
@@ -624,6 +692,23 @@ mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, co
     p.spp = 1; p.first_sample = 0; p.samples_per_item = 1; p.chunks = 1; p.tiles_x = 0x7fffffffu; p.tiles_y = 1;
     p.max_depth = ctx->opts.max_depth; p.flags = ctx->opts.flags & ~MCPT_FLAG_COUNT_TRAVERSAL; p.integrator = MCPT_INTEGRATOR_MIS;
     p.seed_lo = uint32_t(seed); p.seed_hi = uint32_t(seed >> 32);
+    if (ctx->use_wavefront) {
+        // the production pipeline: [wf_shade, wf_trace] iterations over the path pool, item i = entry i of an n x 1 film
+        if (n > 0x3ffffffu) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_paths: too many paths for one call");
+        float4* d_film = nullptr;
+        HIP_TRY(s.out(size_t(n), &d_film));
+        p.probe_n = n; p.probe_o = d_o; p.probe_d = d_d;
+        st = render_wavefront(ctx, p, d_film); if (st != MCPT_OK) return st;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (auto& L : ctx->lanes) { L.last_iterations = 0; L.last_timed = 0; }
+        std::vector<float> film(4 * size_t(n));
+        HIP_TRY(hipMemcpy(film.data(), d_film, film.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) {
+            if (film[4 * size_t(i) + 3] != 1.f) return fail(MCPT_ERR_HIP, "mcpt_probe_paths: a probe path did not finish exactly once");
+            for (int k = 0; k < 3; k++) out_L3[3 * size_t(i) + k] = film[4 * size_t(i) + k];
+        }
+        return MCPT_OK;
+    }
     HIP_TRY(launch_probe_paths(ctx->dev, p, n, d_o, d_d, d_out, d_cnt, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(out_L3, d_out, 3 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));

@@ -90,6 +90,31 @@ DEV void cast_ray(const DevCamera& c, int x, int y, float xi_x, float xi_y, d3& 
 //                                       any-hit  t1 <= t <= t2, |det| >= 1e-6, 0<=u<=1, v>=0, u+v<=1.
 struct TravCount { uint32_t box, tri; };
 
+// Moller-Trumbore against one 48-B {v0, e1, e2} record -- the ONE triangle test of this library, shared by the binary-tree
+// traversal below and the 4-wide wavefront trace kernel (wavefront.hip).  Triangle::hit / isIntersect compute the same
+// quantities in fp64 (Triangle.cpp:48-66, :83-104); the acceptance rules are the reference's, see tri_accept_*.
+struct TriTest { float a, t, u, v; };
+DEV TriTest tri_test(const float4 v0, const float4 e1, const float4 e2, const f3 o, const f3 d) {
+    const float hx = d.y * e2.z - e2.y * d.z, hy = d.z * e2.x - e2.z * d.x, hz = d.x * e2.y - e2.x * d.y;   // h = d x e2
+    TriTest r;
+    r.a = e1.x * hx + e1.y * hy + e1.z * hz;
+    const float sx = o.x - v0.x, sy = o.y - v0.y, sz = o.z - v0.z;
+    const float qx = sy * e1.z - e1.y * sz, qy = sz * e1.x - e1.z * sx, qz = sx * e1.y - e1.x * sy;         // q = s x e1
+    const float inv_a = __builtin_amdgcn_rcpf(r.a);
+    r.u = (sx * hx + sy * hy + sz * hz) * inv_a;
+    r.v = (d.x * qx + d.y * qy + d.z * qz) * inv_a;
+    r.t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv_a;
+    return r;
+}
+// Triangle::isIntersect (Triangle.cpp:85-104): |det| >= 1e-6, 0 <= u <= 1, v >= 0, u + v <= 1, t1 <= t <= t2 (inclusive)
+DEV bool tri_accept_any(const TriTest& r, float tmin, float tmax) {
+    return fabsf(r.a) >= 1e-6f && r.u >= 0.0f && r.u <= 1.0f && r.v >= 0.0f && r.u + r.v <= 1.0f && r.t >= tmin && r.t <= tmax;
+}
+// Triangle::hit (Triangle.cpp:54,66): |a| >= 1e-5, t1 <= t < t2, u, v, 1-u-v >= 0
+DEV bool tri_accept_closest(const TriTest& r, float tmin, float tmax) {
+    return fabsf(r.a) >= 0.00001f && r.t >= tmin && r.t < tmax && r.u >= 0.0f && r.v >= 0.0f && (1.0f - r.u - r.v) >= 0.0f;
+}
+
 template <bool ANY, bool COUNT>
 DEV bool bvh_traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, int skip_tri, int* stk,
                       int& hit_tri, float& hit_t, float& hit_u, float& hit_v, TravCount& tc) {
@@ -137,23 +162,11 @@ DEV bool bvh_traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, in
                 const float4* T = sc.tri_isect + 3 * (size_t)ti;
                 const float4 v0 = T[0], e1 = T[1], e2 = T[2];
                 if (COUNT) tc.tri++;
-                const float hx = d.y * e2.z - e2.y * d.z, hy = d.z * e2.x - e2.z * d.x, hz = d.x * e2.y - e2.x * d.y;   // h = d x e2
-                const float a = e1.x * hx + e1.y * hy + e1.z * hz;
-                const float sx = o.x - v0.x, sy = o.y - v0.y, sz = o.z - v0.z;
-                const float qx = sy * e1.z - e1.y * sz, qy = sz * e1.x - e1.z * sx, qz = sx * e1.y - e1.x * sy;         // q = s x e1
-                const float inv_a = __builtin_amdgcn_rcpf(a);
-                const float u = (sx * hx + sy * hy + sz * hz) * inv_a;
-                const float v = (d.x * qx + d.y * qy + d.z * qz) * inv_a;
-                const float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv_a;
+                const TriTest r = tri_test(v0, e1, e2, o, d);
                 if (ANY) {
-                    if (fabsf(a) >= 1e-6f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && t >= tmin && t <= tmax) {
-                        hit_tri = ti; hit_t = t; hit_u = u; hit_v = v;
-                        return true;
-                    }
+                    if (tri_accept_any(r, tmin, tmax)) { hit_tri = ti; hit_t = r.t; hit_u = r.u; hit_v = r.v; return true; }
                 } else {
-                    if (fabsf(a) >= 0.00001f && t >= tmin && t < tmax && u >= 0.0f && v >= 0.0f && (1.0f - u - v) >= 0.0f) {
-                        tmax = t; hit_tri = ti; hit_t = t; hit_u = u; hit_v = v; found = true;
-                    }
+                    if (tri_accept_closest(r, tmin, tmax)) { tmax = r.t; hit_tri = ti; hit_t = r.t; hit_u = r.u; hit_v = r.v; found = true; }
                 }
             }
             sp--; node = stk[sp * MCPT_BLOCK];

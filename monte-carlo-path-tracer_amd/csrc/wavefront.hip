@@ -250,7 +250,9 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
                 for (uint32_t k = 0; k < wv_; k++) before += s_wave_cnt[k];
                 const uint32_t l = s_base + before + lane_rank(m);
                 const uint32_t item = ((l / MCPT_BLOCK) * WF_ITEM_SHARDS + s_sel) * MCPT_BLOCK + (l % MCPT_BLOCK);
-                if (item < n_items) {
+                if (p.probe_n) {                                            // probe: item = film entry, one sample
+                    if (item < p.probe_n) { id.x = item; id.z = p.first_sample; id.w = p.first_sample + 1u; }
+                } else if (item < n_items) {
                     const uint32_t n_tiles = p.tiles_x * p.tiles_y;
                     const uint32_t wv = item >> 6, il = item & 63u;
                     const uint32_t chunk = wv / n_tiles, tile = wv - chunk * n_tiles;
@@ -270,6 +272,10 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         const Rng4 r = rng_block(id.x, id.y, 0u, p.seed_lo, p.seed_hi);
         const int px = (int)(id.x % (uint32_t)sc.cam.width), py = (int)(id.x / (uint32_t)sc.cam.width);
         d3 eye64;
+        if (p.probe_n) {                                                                        // mcpt_probe_paths: the caller's ray
+            eye64 = mkd(p.probe_o[3 * id.x], p.probe_o[3 * id.x + 1], p.probe_o[3 * id.x + 2]); no = to_f3(eye64);
+            nd = mk3((float)p.probe_d[3 * id.x], (float)p.probe_d[3 * id.x + 1], (float)p.probe_d[3 * id.x + 2]);
+        } else
         cast_ray(sc.cam, px, py, r.v[0], r.v[1], eye64, no, nd);                                // Render.cpp:64
         st_s(&pool.org64[slot], make_double4(eye64.x, eye64.y, eye64.z, 0.0));
         beta = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f); bounce = 0; prev_pdf = 0.f; prev_mirror = false;
@@ -392,7 +398,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     float idx = 0, idy = 0, idz = 0, oodx = 0, oody = 0, oodz = 0, tmax = 0;
     int node = MCPT_NODE_SENTINEL, sp = 1;
     int htri = -1; float ht = 0, hu = 0, hv = 0;
-    uint32_t n_box = 0, n_tri = 0;
+    uint32_t n_box = 0, n_tri = 0, n_spill = 0;     // n_spill: stack entries that went to the global overflow area (COUNT builds)
 #ifdef WF_SCHED_STATS
     uint32_t x_inner = 0, x_leaf = 0, x_refill = 0, l_refill = 0;    // block executions (wave-uniform); n_box / n_tri count lane participations
 #endif
@@ -488,18 +494,11 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #ifndef WF_SCHED_STATS
                     if (COUNT) n_tri++;
 #endif
-                    const float hx = d.y * e2.z - e2.y * d.z, hy = d.z * e2.x - e2.z * d.x, hz = d.x * e2.y - e2.x * d.y;
-                    const float a = e1.x * hx + e1.y * hy + e1.z * hz;
-                    const float sx = o.x - v0.x, sy = o.y - v0.y, sz = o.z - v0.z;
-                    const float qx = sy * e1.z - e1.y * sz, qy = sz * e1.x - e1.z * sx, qz = sx * e1.y - e1.x * sy;
-                    const float inv_a = __builtin_amdgcn_rcpf(a);
-                    const float u = (sx * hx + sy * hy + sz * hz) * inv_a;
-                    const float v = (d.x * qx + d.y * qy + d.z * qz) * inv_a;
-                    const float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv_a;
+                    const TriTest r = tri_test(v0, e1, e2, o, d);
                     if (any) {                                           // Triangle::isIntersect
-                        if (fabsf(a) >= 1e-6f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && t >= 1e-4f && t <= tmax) { blocked = true; done = true; }
+                        if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; }
                     } else {                                             // Triangle::hit
-                        if (fabsf(a) >= 0.00001f && t >= 1e-4f && t < tmax && u >= 0.0f && v >= 0.0f && (1.0f - u - v) >= 0.0f) { tmax = t; htri = ti; ht = t; hu = u; hv = v; }
+                        if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ti; ht = r.t; hu = r.u; hv = r.v; }
                     }
                 }
                 if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
@@ -564,9 +563,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     node = hit0 ? cd0 : below;
                     sp -= hit0 ? 0 : 1;
                 } else {                                                   // rare: near the LDS limit -> entries may go to the overflow area
-                    if (h3) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd3; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd3; sp++; }
-                    if (h2) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd2; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd2; sp++; }
-                    if (h1) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd1; else ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd1; sp++; }
+                    if (h3) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd3; else { ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd3; if (COUNT) n_spill++; } sp++; }
+                    if (h2) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd2; else { ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd2; if (COUNT) n_spill++; } sp++; }
+                    if (h1) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd1; else { ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd1; if (COUNT) n_spill++; } sp++; }
                     if (key0 < inf) node = cd0;
                     else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
                 }
@@ -580,10 +579,11 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     }
 
     if (COUNT) {
-        unsigned long long b = n_box, t = n_tri;
-        for (int off = 32; off > 0; off >>= 1) { b += __shfl_xor(b, off, 64); t += __shfl_xor(t, off, 64); }
+        unsigned long long b = n_box, t = n_tri, sx = n_spill;
+        for (int off = 32; off > 0; off >>= 1) { b += __shfl_xor(b, off, 64); t += __shfl_xor(t, off, 64); sx += __shfl_xor(sx, off, 64); }
         if (lane == 0) {
             DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1)); atomicAdd(&g->box_tests, b); atomicAdd(&g->tri_tests, t);
+            if (sx) atomicAdd(&g->stack_spills, sx);
 #ifdef WF_SCHED_STATS   // tools/sched_stats.py: the shade-side counters are re-purposed in this diagnostic build
             atomicAdd(&g->paths, wall_clock64() - t_start);            // wave lifetime in 10-ns ticks
             atomicAdd(&g->shaded_hits, (unsigned long long)x_inner); atomicAdd(&g->texel_fetches, (unsigned long long)x_leaf);

@@ -181,6 +181,106 @@ def test_probe_trace_vs_reference(pkg, paths):
     assert (anyh == p["cs_ray_any"]).mean() >= 0.999
 
 
+def _trace4_vs_reference(r, p):
+    t, tri, u, v = r.probe_trace4(p["cs_ray_o"], p["cs_ray_d"])
+    anyh = r.probe_trace4(p["cs_ray_o"], p["cs_ray_d"], t2=p["cs_ray_t2"], any_hit=True)[1]
+    ref_tri = p["cs_ray_rec"][:, 11].astype(np.int32); ref_hit = p["cs_ray_hit"] == 1
+    same = (tri == np.where(ref_hit, ref_tri, -1))
+    assert same.mean() >= 0.999, same.mean()
+    ok = same & ref_hit
+    assert np.allclose(t[ok], p["cs_ray_rec"][ok, 0], rtol=2e-5, atol=2e-6)
+    assert (anyh == p["cs_ray_any"]).mean() >= 0.999, (anyh == p["cs_ray_any"]).mean()
+    return t, tri, u, v, anyh
+
+
+@pytest.mark.parametrize("tree", ["host-sah", "device-lbvh"])
+@pytest.mark.parametrize("grid", [0, 1])
+def test_probe_trace4_hot_kernel_vs_reference(pkg, paths, tree, grid):
+    """The PRODUCTION traversal (wf_trace_kernel: 4-wide quantised nodes, LDS top levels, LDS + overflow stack, chunked ray list)
+    on the reference's own 4 000 rays: BVH::hit (same triangle, same t) and BVH::has_hit (same verdict with the reference's t2) on
+    >= 99.9 % of rays -- with the host SAH tree and the device-built LBVH, on the full persistent grid and on ONE block
+    (MCPT_WF_GRID=1: every chunk of the ray list comes from the atomic cursor)."""
+    if grid: os.environ["MCPT_WF_GRID"] = str(grid)
+    try:
+        r = pkg.Renderer(pkg.scenes.cornell_box_small(64, 64), flags=pkg.FLAG_GPU_BVH_BUILD if tree == "device-lbvh" else 0)
+    finally:
+        os.environ.pop("MCPT_WF_GRID", None)
+    t4, tri4, u4, v4, any4 = _trace4_vs_reference(r, paths)
+    # and against the binary-tree cross-check traversal: identical triangle test code, so identical numbers wherever both pick the same triangle
+    t2_, tri2, u2, v2 = r.probe_trace(paths["cs_ray_o"], paths["cs_ray_d"])
+    r.close()
+    same = tri4 == tri2
+    assert same.mean() >= 0.9995
+    assert np.array_equal(t4[same], t2_[same]) and np.array_equal(u4[same], u2[same]) and np.array_equal(v4[same], v2[same])
+
+
+def _needle_forest(pkg, n_needles=6000, seed=5):
+    """Long thin triangles along x scattered over a 1 x 1 cross-section: a ray crossing the bundle diagonally in the y-z plane enters
+    every child box of every level and hits almost nothing, so the near-first traversal keeps up to 3 deferred children per level."""
+    rng = np.random.RandomState(seed)
+    m = pkg.scenes._Mesh()
+    for _ in range(n_needles):
+        y, z = rng.uniform(0, 1, 2); dy, dz = rng.normal(size=2) * 2e-4
+        a = m.add_vertex((0.0, y, z), (0, 1, 0), (0, 0)); b = m.add_vertex((4.0, y + dy, z + dz), (0, 1, 0), (1, 0))
+        c = m.add_vertex((2.0, y + 3e-4, z + 3e-4), (0, 1, 0), (0.5, 1))
+        m.add_tri(a, b, c, 0)
+    m.add_quad((-1, 3, -1), (5, 3, -1), (5, 3, 2), (-1, 3, 2), (0, -1, 0), 1)
+    mats = [pkg.scenes.Material("needle", kd=(0.5, 0.5, 0.5)), pkg.scenes.Material("light", kd=(0.0, 0.0, 0.0), radiance=(5.0, 5.0, 5.0))]
+    return m.finish("needles", mats, pkg.scenes._qcam((2.0, 0.5, 4.0), (2.0, 0.5, 0.0), (0, 1, 0), 40.0, 16, 16))
+
+
+@pytest.mark.parametrize("tree", ["host-sah", "device-lbvh"])
+def test_probe_trace4_overflow_stack_and_random_rays(pkg, orc, tree):
+    """Rays that push the per-lane stack past its 12 LDS entries into the global overflow area (counted by the kernel), compared with
+    the binary-tree traversal on 200 000 rays and with the fp64 oracle (the reference's BVH::hit restated) on 3 000 of them."""
+    scene = _needle_forest(pkg)
+    rng = np.random.RandomState(11)
+    n = 200_000
+    o = np.stack([rng.uniform(0.2, 3.8, n), rng.uniform(-0.5, -0.1, n), rng.uniform(-0.5, 1.5, n)], 1)
+    tgt = np.stack([o[:, 0] + rng.normal(size=n) * 0.05, rng.uniform(1.1, 1.5, n), rng.uniform(-0.5, 1.5, n)], 1)
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    fl = pkg.FLAG_COUNT_TRAVERSAL | (pkg.FLAG_GPU_BVH_BUILD if tree == "device-lbvh" else 0)
+    r = pkg.Renderer(scene, flags=fl)
+    t4, tri4, u4, v4 = r.probe_trace4(o, d)
+    c = r.counters()
+    t2_, tri2, u2, v2 = r.probe_trace(o, d)
+    tlim = rng.uniform(0.5, 3.0, n)
+    any4 = r.probe_trace4(o, d, t2=tlim, any_hit=True)[1]
+    any2 = r.probe_trace(o, d, t2=tlim, any_hit=True)[1]
+    r.close()
+    print(tree, "stack spills", c.stack_spills, "box tests/ray %.1f" % (c.box_tests / n), "hit rate %.3f" % (tri4 >= 0).mean())
+    assert c.stack_spills > 0, "the workload did not reach the overflow stack"
+    same = tri4 == tri2
+    assert same.mean() >= 0.9999, same.mean()
+    assert np.array_equal(t4[same], t2_[same]) and np.array_equal(u4[same], u2[same])
+    assert (any4 == any2).mean() >= 0.9999
+    o_ = orc.Oracle(scene)
+    k = 3000
+    ref = [o_.bvh_hit(o[i], d[i]) for i in range(k)]
+    ref_hit = np.array([h for h, _ in ref]) == 1; ref_t = np.array([rec[0] for _, rec in ref]); ref_tri = np.array([int(rec[11]) for _, rec in ref])
+    agree = (tri4[:k] >= 0) == ref_hit
+    assert agree.mean() >= 0.998, agree.mean()                            # needles are 3e-4 wide: fp32 vs fp64 at their edges
+    both = agree & ref_hit & (tri4[:k] == ref_tri)
+    assert both.sum() >= 0.99 * ref_hit.sum() and np.allclose(t4[:k][both], ref_t[both], rtol=2e-5, atol=2e-6)
+
+
+def test_trace4_equals_binary_traversal_on_bench_scene(pkg):
+    """1 000 000 random rays through S-cornell (39 612 triangles, the bench scene): production kernel == cross-check traversal."""
+    scene = pkg.scenes.cornell_box(64, 64)
+    rng = np.random.RandomState(2)
+    n = 1_000_000
+    o = rng.uniform(0.02, 0.98, (n, 3)); d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = pkg.Renderer(scene)
+    t4, tri4, u4, v4 = r.probe_trace4(o, d); t2_, tri2, u2, v2 = r.probe_trace(o, d)
+    tlim = rng.uniform(0.05, 1.0, n)
+    any4 = r.probe_trace4(o, d, t2=tlim, any_hit=True)[1]; any2 = r.probe_trace(o, d, t2=tlim, any_hit=True)[1]
+    r.close()
+    same = tri4 == tri2
+    assert (tri4 >= 0).all() and same.mean() >= 0.99999, same.mean()      # closed box: every ray hits; ties on shared edges only
+    assert np.array_equal(t4[same], t2_[same]) and np.array_equal(u4[same], u2[same]) and np.array_equal(v4[same], v2[same])
+    assert (any4 == any2).mean() >= 0.99999
+
+
 def test_probe_bsdf_vs_reference(pkg, kats):
     k = kats
     sel = k["bsdf_kind"] != 3
@@ -215,13 +315,15 @@ def test_probe_sample_light_vs_reference(pkg, paths):
     assert set(np.unique(out[:, 8])) == light_faces                          # the two light triangles, reported in face order
 
 
-def test_probe_paths_vs_oracle(pkg, orc):
+@pytest.mark.parametrize("pipeline", ["wave", "mega"])
+def test_probe_paths_vs_oracle(pkg, orc, pipeline):
+    """Whole paths from given rays: the production wavefront pipeline (and the cross-check megakernel) against the oracle."""
     scene = pkg.scenes.cornell_box_small(64, 64)
     flags = pkg.FLAG_CORRECT_SHADOW_T2
     rng = np.random.RandomState(3)
     n = 2000
     o = rng.uniform(0.1, 0.9, (n, 3)); d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
-    r = _renderer(pkg, scene, "mega", max_depth=6, flags=flags)
+    r = _renderer(pkg, scene, pipeline, max_depth=6, flags=flags)
     got = r.probe_paths(o, d, seed=42); r.close()
     oc = orc.Oracle(scene, max_depth=6, flags=flags)
     want = np.array([oc.trace_path_counter(o[i], d[i], i, 42) for i in range(n)])
@@ -269,13 +371,41 @@ def test_external_accumulator_and_stream(pkg):
     scene = pkg.scenes.open_box(16, 16)
     r = pkg.Renderer(scene, max_depth=4)
     buf = torch.zeros(16 * 16 * 4, dtype=torch.float32, device="cuda")
-    r.bind_accum(buf.data_ptr()); r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.bind_accum(buf.data_ptr()); r.set_torch_stream(torch.cuda.current_stream())     # torch's default stream = the legacy null stream
     r.render(4, seed=1); r.sync(); torch.cuda.synchronize()
     a = buf.cpu().numpy().reshape(16, 16, 4)
     assert np.all(a[..., 3] == 4) and a[..., :3].sum() > 0
     r.bind_accum(0); r.set_stream(0)
     assert not r.read_accum().any()                                     # the internal buffer was never touched
     r.close()
+
+
+@pytest.mark.parametrize("which", ["side", "null"])
+def test_render_is_stream_ordered_with_the_callers_stream(pkg, which):
+    """bench.py's usage: film clear, render and a read of the film on ONE caller stream, with long kernels queued in front.  If the
+    library launched on its own stream instead (handle 0 used to mean that), the render would race the clear and the clone."""
+    import torch
+    scene = pkg.scenes.open_box(64, 64)
+    r = pkg.Renderer(scene, max_depth=4)
+    buf = torch.zeros(64 * 64 * 4, dtype=torch.float32, device="cuda")
+    r.bind_accum(buf.data_ptr())
+    s = torch.cuda.Stream() if which == "side" else torch.cuda.default_stream()
+    r.set_torch_stream(s)
+    big = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for _ in range(30):
+            big = (big @ big) * 1e-3                 # ~100 ms of queued work in front of the clear
+        buf.fill_(7.0)
+        buf.zero_()
+        r.render(4, seed=1)
+        snap = buf.clone()                           # ordered after the render's join on the same stream
+        buf.zero_()
+    s.synchronize(); torch.cuda.synchronize()
+    a = snap.cpu().numpy().reshape(64, 64, 4)
+    assert np.all(a[..., 3] == 4), np.unique(a[..., 3])
+    assert not buf.cpu().numpy().any()
+    r.bind_accum(0); r.set_stream(0); r.close()
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE.json sizes: properties
@@ -330,6 +460,56 @@ def test_full_size_properties_other_configs(pkg, name, kw, res, depth):
     assert 2.0 < c.rays / c.paths < 12.0 and c.self_shadow_hits <= c.self_shadow_tests
     m = (whole[..., :3] / 8).mean()
     assert 0.01 < m < 10.0
+
+
+# ------------------------------------------------------------------------------------------------ configs[4] (C5): the HBM-bound case
+@pytest.fixture(scope="module")
+def c5_scene(pkg):
+    """S-bath stress at BASELINE.json configs[4] size: 3840x2160, 4.05 M triangles (2.75 GB of scene on the device: 4-wide nodes +
+    triangle records = 330 MB, beyond L2 and the 256 MB Infinity Cache -> the trace kernel takes its whole-chip grid)."""
+    return pkg.scenes.bathroom_stress(3840, 2160, detail=420)
+
+
+def test_c5_full_size_properties(pkg, c5_scene):
+    """configs[4] geometry at reduced spp, depth 16: count plane, finiteness, additivity of sample ranges, ray accounting, BVH
+    invariants -- the size-independent properties, at the size where BVH_node::hit (BVH.cpp:95-113) stops being cache-resident."""
+    scene = c5_scene
+    assert scene.n_faces >= 4_000_000
+    r = pkg.Renderer(scene, max_depth=16)
+    info = r.info()
+    assert info.n_tris == scene.n_faces and info.bvh_depth <= 30 and info.max_leaf <= 4
+    assert info.n_nodes * 64 + info.n_tris * 48 > 256 << 20           # traversal data larger than the Infinity Cache
+    r.render(2, seed=3, first_sample=0); r.render(2, seed=3, first_sample=2); ab = r.read_accum()
+    r.clear(); r.reset_counters(); r.render(4, seed=3); whole = r.read_accum(); c = r.counters(); r.close()
+    assert np.all(whole[..., 3] == 4) and np.all(ab[..., 3] == 4) and np.isfinite(whole).all()
+    assert np.allclose(ab, whole, rtol=1e-4, atol=1e-4)
+    assert c.paths == 3840 * 2160 * 4 == c.rays_primary
+    assert 2.0 < c.rays / c.paths < 14.0 and c.self_shadow_hits <= c.self_shadow_tests
+    m = (whole[..., :3] / 4).mean((0, 1))
+    print("C5 image mean", m, "rays/path %.2f" % (c.rays / c.paths), "kernel %.1f ms" % c.kernel_ms, "%.0f Mray/s" % (c.rays / c.kernel_ms / 1e3))
+    assert np.all(m > 0.05) and np.all(m < 10.0)
+
+
+def test_c5_same_seed_vs_oracle_small_view(pkg, orc, c5_scene):
+    """The SAME 4 M-triangle scene at depth 16 through a 64x36 film, same counter-based seed, against the fp64 oracle (the
+    reference's midpoint BVH + unordered recursion restated): deep tree, the non-cache-resident trace grid and the overflow stack
+    against fp64, which the full-size property test cannot show."""
+    scene = c5_scene.with_resolution(64, 36)
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    spp = 8
+    r = pkg.Renderer(scene, max_depth=16, flags=flags | pkg.FLAG_COUNT_TRAVERSAL)
+    r.render(spp, seed=55); g = r.read_accum(); c = r.counters(); r.close()
+    o = orc.Oracle(scene, max_depth=16, flags=flags)
+    cpu, oc, secs = o.render(spp, seed=55); o.close()
+    gm, cm = g[..., :3] / spp, cpu[..., :3] / spp
+    frac = _frac_beyond(gm, cm)
+    print("C5 small view: pixels beyond tolerance %.3f%%  mean gpu %s cpu %s  box tests/ray %.1f tri tests/ray %.2f spills %d  oracle %.1f s" % (
+        100 * frac, gm.mean((0, 1)), cm.mean((0, 1)), c.box_tests / c.rays, c.tri_tests / c.rays, c.stack_spills, secs))
+    assert np.all(g[..., 3] == spp)
+    assert frac <= 0.02
+    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=1e-2)
+    assert c.rays_primary == oc["rays_primary"] == 64 * 36 * spp
+    assert abs(int(c.rays_continuation) - oc["rays_continuation"]) <= 0.01 * oc["rays_continuation"]
 
 
 def test_smoke_entry_point():
