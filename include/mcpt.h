@@ -112,6 +112,7 @@ typedef struct mcpt_counters {
     double   shade_ms_total;    /* ... and of the shade kernel since the last reset (0 when detailed timing is off) */
     uint64_t iterations;        /* [shade, trace] iterations since the last reset (each is one launch of either kernel) */
     uint64_t stack_spills;      /* traversal-stack entries that left LDS for the global overflow area (only with COUNT_TRAVERSAL) */
+    uint64_t debug[4];          /* diagnostic library builds only (tools/sched_stats.py); 0 otherwise */
 } mcpt_counters;
 
 typedef struct mcpt_scene_info {

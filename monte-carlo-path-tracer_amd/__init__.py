@@ -67,7 +67,7 @@ class Counters(C.Structure):
                 ("self_shadow_tests", C.c_uint64), ("self_shadow_hits", C.c_uint64),
                 ("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("launches", C.c_uint64),
                 ("trace_ms_total", C.c_double), ("shade_ms_total", C.c_double), ("iterations", C.c_uint64),
-                ("stack_spills", C.c_uint64)]
+                ("stack_spills", C.c_uint64), ("debug", C.c_uint64 * 4)]
 
     @property
     def rays(self) -> int:
@@ -176,6 +176,8 @@ def load_library() -> C.CDLL:
         "mcpt_probe_rng": [vp, C.c_uint32, vp, C.c_uint64, vp],
     }
     for name, args in sigs.items():
+        if not hasattr(lib, name) and "MCPT_LIB_PATH" in os.environ:
+            continue                                     # developer A/B against an older build of the library
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int

@@ -12,7 +12,9 @@
 //                f4[2] = c0.lo.z c0.hi.z c1.lo.z c1.hi.z
 //                f4[3] = (int) child0, child1, 0, 0     child >= 0: inner node index; child < 0: leaf, ~child =
 //                                                         first_triangle << 3 | count  (count <= 7, leaf order)
-//   tri_isect  48 B / triangle   : v0.xyz,_ | e1.xyz,_ | e2.xyz,_   (fp32; e = float(v_k - v_0) like Triangle.cpp:25-26)
+//   tri_isect  48 B / triangle   : v0.xyz,c | e1.xyz,_ | e2.xyz,_   (fp32; e = float(v_k - v_0) like Triangle.cpp:25-26)
+//                                  c = uint bits HIT_CLASS_* << 28: the lobe set BSDF::BSDF will build for this triangle's
+//                                  material (BSDF.cpp:95-107); the trace kernel ORs it into the triangle index of a closest hit
 //   tri_shade  64 B / triangle   : n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y material
 //   tri_pos64  72 B / triangle   : v0 v1 v2 in fp64 -- read once per shaded hit to form the fp64 hit point the
 //                                  reference's shadow-ray self-occlusion depends on (SURVEY A-9), and per light sample
@@ -33,6 +35,11 @@
 #define MCPT_TOP_NODES 256         // nodes numbered breadth-first by the builder; the trace kernel serves them from LDS
 #endif
 #define MCPT_NODE_SENTINEL ((int)0x80000000)
+#define HIT_CLASS_SHIFT 28         // pool.hit.x = triangle index (< 2^28, checked at scene build) | HIT_CLASS_* << 28; -1 = miss
+#define HIT_TRI_MASK 0x0fffffff
+#define HIT_CLASS_DIFFUSE 0u       // Diffuse lobe only                         (BSDF.cpp:105)
+#define HIT_CLASS_PHONG 1u         // Blinn-Phong + Diffuse                     (BSDF.cpp:99-105)
+#define HIT_CLASS_MIRROR 2u        // specular_reflection + Diffuse (Ns >= 10000, BSDF.cpp:97-98)
 
 struct DevMaterial {               // Material (model.h:32-40) + its Texture header (model.h:21-30)
     float ks[3]; float ns;
@@ -101,4 +108,5 @@ struct RenderParams {
 struct DevCounters {               // mirrors the integer part of mcpt_counters
     unsigned long long paths, rays_primary, rays_continuation, rays_shadow, box_tests, tri_tests, shaded_hits,
         texel_fetches, self_shadow_tests, self_shadow_hits, stack_spills;
+    unsigned long long debug[4];   // diagnostic builds (-DWF_SCHED_STATS) only
 };

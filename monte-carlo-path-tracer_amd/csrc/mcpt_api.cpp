@@ -237,12 +237,12 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             c->lanes.resize(n_lanes);
             for (auto& L : c->lanes) {
                 L.pool.P = P;
-                L.pool_bufs.resize(12);
-                void** dst[12] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sh_d, (void**)&L.pool.nee,
+                L.pool_bufs.resize(11);
+                void** dst[11] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sh_d, (void**)&L.pool.nee,
                                   (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
-                                  (void**)&L.pool.org64, (void**)&L.pool.shadow_count};
-                for (int i = 0; i < 12; i++) {
-                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 11 ? size_t(P / MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * (i == 10 ? 32 : 16);
+                                  (void**)&L.pool.shadow_count};
+                for (int i = 0; i < 11; i++) {
+                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * 16;
                     if ((e = L.pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
                     if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
                     *dst[i] = L.pool_bufs[i].p;
@@ -521,12 +521,12 @@ mcpt_status mcpt_get_counters(mcpt_ctx* ctx, mcpt_counters* out) {
     for (const DevCounters& r : rep) {
         d.paths += r.paths; d.rays_primary += r.rays_primary; d.rays_continuation += r.rays_continuation; d.rays_shadow += r.rays_shadow;
         d.box_tests += r.box_tests; d.tri_tests += r.tri_tests; d.shaded_hits += r.shaded_hits; d.texel_fetches += r.texel_fetches;
-        d.self_shadow_tests += r.self_shadow_tests; d.self_shadow_hits += r.self_shadow_hits; d.stack_spills += r.stack_spills;
+        d.self_shadow_tests += r.self_shadow_tests; d.self_shadow_hits += r.self_shadow_hits; d.stack_spills += r.stack_spills; for (int q = 0; q < 4; q++) d.debug[q] += r.debug[q];
     }
     std::memset(out, 0, sizeof *out);
     out->paths = d.paths; out->rays_primary = d.rays_primary; out->rays_continuation = d.rays_continuation; out->rays_shadow = d.rays_shadow;
     out->box_tests = d.box_tests; out->tri_tests = d.tri_tests; out->shaded_hits = d.shaded_hits; out->texel_fetches = d.texel_fetches;
-    out->self_shadow_tests = d.self_shadow_tests; out->self_shadow_hits = d.self_shadow_hits; out->stack_spills = d.stack_spills;
+    out->self_shadow_tests = d.self_shadow_tests; out->self_shadow_hits = d.self_shadow_hits; out->stack_spills = d.stack_spills; for (int q = 0; q < 4; q++) out->debug[q] = d.debug[q];
     out->kernel_ms = ctx->last_kernel_ms; out->kernel_ms_total = ctx->total_kernel_ms; out->launches = ctx->launches;
     out->trace_ms_total = ctx->total_trace_ms; out->shade_ms_total = ctx->total_shade_ms; out->iterations = ctx->total_iterations;
     return MCPT_OK;
@@ -597,7 +597,7 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
     const uint32_t P = uint32_t(((uint64_t(n) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
     if (P > pool.P) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_trace4: more rays than pool slots");
     pool.P = P;
-    std::vector<float> ro(4 * size_t(P), 0.f), rd(4 * size_t(P), 0.f), sd(4 * size_t(P), 0.f), nee(4 * size_t(P), 0.f), hit(4 * size_t(P), 0.f);
+    std::vector<float> ro(4 * size_t(P), 0.f), rd(4 * size_t(P), 0.f), sd(4 * size_t(P), 0.f), hit(4 * size_t(P), 0.f);
     std::vector<uint32_t> queue(P, 0u), qcount(P / MCPT_BLOCK, 0u);
     const int32_t no_skip = -1; float no_skip_f; std::memcpy(&no_skip_f, &no_skip, 4);
     for (uint32_t i = 0; i < P; i++) {
@@ -607,15 +607,15 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
         for (int k = 0; k < 3; k++) { o4[k] = float(origin[3 * size_t(i) + k]); d4[k] = float(dir[3 * size_t(i) + k]); s4[k] = d4[k]; }
         if (any_hit) {
             s4[3] = t2[i] > 3.0e38 ? 3.0e38f : float(t2[i]);
-            nee[4 * size_t(i)] = 1.f;                                   // unoccluded => L.x becomes 1
             queue[i] = i;                                               // shade block b queues its own slots in order
             qcount[i / MCPT_BLOCK]++;
-        } else d4[3] = 1.f;                                             // "an extend ray is pending"
+        } else { const uint32_t one = 1u; std::memcpy(&d4[3], &one, 4); }   // bit 0 of ray_d.w: "an extend ray is pending"
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(pool.ray_o, ro.data(), ro.size() * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(pool.ray_d, rd.data(), rd.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(pool.sh_d, sd.data(), sd.size() * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(pool.nee, nee.data(), nee.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(pool.L, 0, size_t(P) * 16)); HIP_TRY(hipMemset(pool.hit, 0xff, size_t(P) * 16));
+    HIP_TRY(hipMemcpy(pool.sh_d, sd.data(), sd.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(pool.hit, 0xff, size_t(P) * 16));
+    HIP_TRY(hipMemset(pool.nee, 0, size_t(P) * 16));                 // nee.w == 0 afterwards <=> the trace kernel did not flag the ray as blocked
     HIP_TRY(hipMemcpy(pool.shadow_queue, queue.data(), queue.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pool.shadow_count, qcount.data(), qcount.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(L.ctl_buf.p, 0, sizeof(IterCtl)));
@@ -624,8 +624,11 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
                             static_cast<int*>(L.ovf_buf.p), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (any_hit) {
-        HIP_TRY(hipMemcpy(hit.data(), pool.L, hit.size() * 4, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < n; i++) { out_tri[i] = hit[4 * size_t(i)] == 1.f ? 0 : 1; out_t[i] = 0.f; out_u[i] = 0.f; out_v[i] = 0.f; }
+        HIP_TRY(hipMemcpy(hit.data(), pool.nee, hit.size() * 4, hipMemcpyDeviceToHost));     // blocked <=> the trace kernel set nee.w
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t flag; std::memcpy(&flag, &hit[4 * size_t(i) + 3], 4);
+            out_tri[i] = flag ? 1 : 0; out_t[i] = 0.f; out_u[i] = 0.f; out_v[i] = 0.f;
+        }
     } else {
         if (ctx->h_tri_face.empty()) {
             ctx->h_tri_face.resize(size_t(ctx->dev.n_tris));
@@ -634,6 +637,7 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
         HIP_TRY(hipMemcpy(hit.data(), pool.hit, hit.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n; i++) {
             int32_t tri; std::memcpy(&tri, &hit[4 * size_t(i)], 4);
+            if (tri >= 0) tri &= HIT_TRI_MASK;                          // the upper bits carry the hit's lobe class for the shade kernel
             if (tri >= ctx->dev.n_tris) return fail(MCPT_ERR_HIP, "mcpt_probe_trace4: trace kernel returned an out-of-range triangle");
             out_tri[i] = tri < 0 ? -1 : ctx->h_tri_face[size_t(tri)];
             out_u[i] = tri < 0 ? 0.f : hit[4 * size_t(i) + 1]; out_v[i] = tri < 0 ? 0.f : hit[4 * size_t(i) + 2]; out_t[i] = tri < 0 ? 0.f : hit[4 * size_t(i) + 3];

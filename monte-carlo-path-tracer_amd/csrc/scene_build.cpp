@@ -430,7 +430,9 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         const double* v0 = d->vertex + 3 * c[0]; const double* v1 = d->vertex + 3 * c[4]; const double* v2 = d->vertex + 3 * c[8];
         const double* n0 = d->normal + 3 * c[1]; const double* n1 = d->normal + 3 * c[5]; const double* n2 = d->normal + 3 * c[9];
         const double* t0_ = d->texcoord + 2 * c[2]; const double* t1_ = d->texcoord + 2 * c[6]; const double* t2_ = d->texcoord + 2 * c[10];
-        out.tri_isect[3 * size_t(i) + 0] = {float(v0[0]), float(v0[1]), float(v0[2]), 0.f};
+        const uint32_t mflags = out.mats[size_t(c[3])].flags;
+        const uint32_t lobe_class = !(mflags & MAT_HAS_SPEC) ? HIT_CLASS_DIFFUSE : (mflags & MAT_MIRROR) ? HIT_CLASS_MIRROR : HIT_CLASS_PHONG;
+        out.tri_isect[3 * size_t(i) + 0] = {float(v0[0]), float(v0[1]), float(v0[2]), as_float(int(lobe_class << HIT_CLASS_SHIFT))};
         out.tri_isect[3 * size_t(i) + 1] = {float(v1[0] - v0[0]), float(v1[1] - v0[1]), float(v1[2] - v0[2]), 0.f};
         out.tri_isect[3 * size_t(i) + 2] = {float(v2[0] - v0[0]), float(v2[1] - v0[1]), float(v2[2] - v0[2]), 0.f};
         out.tri_shade[4 * size_t(i) + 0] = {float(n0[0]), float(n0[1]), float(n0[2]), float(t0_[0])};

@@ -12,15 +12,15 @@
 
 struct PathPool {
     float4* ray_o;      // extend-ray origin xyz (= previous path vertex) | w: int bits = light triangle the pending shadow ray must skip
-    float4* ray_d;      // extend-ray direction xyz                        | w: 1.0f if an extend ray is pending this iteration, else 0
-    float4* hit;        // written by trace: int bits tri (leaf order, -1 = miss), u, v, t
+    float4* ray_d;      // extend-ray direction xyz                        | w: uint bits, bit 0 = an extend ray is pending this iteration
+    float4* hit;        // written by trace: int bits tri (leaf order) | lobe class << 28 (-1 = miss), u, v, t
     float4* sh_d;       // pending shadow ray: direction xyz, t2 (origin = ray_o.xyz)
-    float4* nee;        // radiance the pending shadow ray carries if unoccluded (xyz)
+    float4* nee;        // radiance the pending shadow ray carries if unoccluded (xyz) | w: uint, set non-zero by trace if the ray is
+                        // blocked; otherwise xyz is added to L by the NEXT shade call
     float4* L;          // radiance of the current path so far xyz | w: pdf of the BSDF sample that produced the extend ray
-    float4* beta;       // path throughput xyz | w: uint bits  state(2) | prev_mirror(1) | bounce << 8
+    float4* beta;       // path throughput xyz | w: uint bits  state(2) | prev_mirror(1) | shadow ray pending(1) | bounce << 8
     float4* sum;        // item accumulator: sum of finished samples xyz | w: number of finished samples
     uint4* ids;         // pixel, current sample index, next sample index, end sample index
-    double4* org64;     // fp64 origin of the extend ray (reference: Ray::start is a dvec3); read only by shade
     uint32_t* shadow_queue;   // slots with a pending shadow ray: shade block b owns entries [256 b, 256 b + shadow_count[b]) -- no atomics
     uint32_t* shadow_count;   // entries each shade block wrote this iteration
     uint32_t P;         // slots
@@ -29,8 +29,8 @@ struct PathPool {
 #define WF_SHARDS 8          // shadow-queue shards (block b appends to shard b % 8: 8x less contention on the cursor)
 #define WF_COUNTER_REPLICAS 1024
 #define WF_ITEM_SHARDS 64
-#define WF_LDS_MATS 32        // material / light tables up to these sizes are staged in LDS by the shade kernel
-#define WF_LDS_LIGHTS 16
+#define WF_LDS_MATS 16        // material / light tables up to these sizes are staged in LDS by the shade kernel
+#define WF_LDS_LIGHTS 8
 
 struct IterCtl {        // indexed [iteration & 3]; shade(it) zeroes entry (it+1)&3 for the next iteration
     uint32_t trace_head[4];

@@ -57,78 +57,182 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {            // num
 __device__ __forceinline__ uint32_t wave_first(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ====================================================================================================== shade
+// Branch-sorted shading.  The reference assembles a different lobe set per material (BSDF.cpp:95-107) and a path may end at
+// every vertex (miss, Russian roulette, depth), so lanes that simply own "their" slot diverge: measured 0.48 VALU lane utilisation
+// with one lane per slot in slot order.  Here a 256-thread block first CLASSIFIES its 256 slots from three coalesced 16-B records
+// (state word + throughput, hit record, ids), sorts the slot indices by class through LDS (stable counting sort: ballots + one
+// 20-entry scan), and only then does lane j pick up slot perm[j] -- so whole waves run the same branch:
+//
+//   K_END     nothing to shade: dead / draining slot, or the extend ray missed            -> finish the sample, regenerate
+//   K_EMIT    the path ends at this vertex (Russian roulette or depth) -- both are functions of the slot's throughput, bounce
+//             and RNG key, so they are decided during classification -- but the reference still adds the emitter-MIS term
+//             of this hit first (Render.cpp:146-162 precedes :164-170)                    -> hit record + emission, regenerate
+//   K_DIFF    full vertex, Diffuse lobe only  (BSDF.cpp:105)
+//   K_PHONG   full vertex, Blinn-Phong + Diffuse (BSDF.cpp:99-105)
+//   K_MIRROR  full vertex, perfect mirror + Diffuse (BSDF.cpp:97-98)
+//
+// The lobe class of a hit comes with the hit: the trace kernel ORs the two class bits stored in the triangle's intersection
+// record (tri_isect[].v0.w) into the triangle index it writes back -- no extra fetch.  All slot traffic of the permuted lanes stays
+// inside the block's own 256-slot window of each pool array (the same cache lines the block would read in slot order).
 #ifndef MCPT_SHADE_MIN_WAVES
 #define MCPT_SHADE_MIN_WAVES 1
 #endif
+#define K_END 0u
+#define K_EMIT 1u
+#define K_DIFF 2u      // K_DIFF + lobe class (HIT_CLASS_*) = K_PHONG, K_MIRROR
+#define K_COUNT 5u
 template <bool COUNT>
 __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_kernel(DevScene sc, RenderParams p, PathPool pool, IterCtl* ctl, uint32_t it, uint32_t n_items,
                                                               float4* __restrict__ accum, DevCounters* gcnt) {
-    const uint32_t slot = blockIdx.x * MCPT_BLOCK + threadIdx.x;           // pool.P is a multiple of MCPT_BLOCK
-    const uint32_t lane = threadIdx.x & 63;
-    if (slot == 0) { const uint32_t n = (it + 1) & 3; ctl->trace_head[n] = 0; ctl->any_active[n] = 0; }
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t base = blockIdx.x * MCPT_BLOCK;                             // pool.P is a multiple of MCPT_BLOCK
+    if (base + tid == 0) { const uint32_t n = (it + 1) & 3; ctl->trace_head[n] = 0; ctl->any_active[n] = 0; }
     __shared__ uint32_t s_wave_cnt[MCPT_BLOCK / 64];
     __shared__ uint32_t s_base, s_sel;
+    // the whole slot state of the block's 256-slot window, fetched coalesced in ONE batch by the slots' own lanes and handed to the
+    // lanes that will process them through LDS: no dependent second round of (gathering) global loads after the sort ...
+    __shared__ float4 s_beta[MCPT_BLOCK], s_hit[MCPT_BLOCK], s_L[MCPT_BLOCK], s_rd[MCPT_BLOCK], s_nee[MCPT_BLOCK], s_ro[MCPT_BLOCK];
+    __shared__ uint4 s_ids[MCPT_BLOCK];
+    // ... and the way back: the processing lane leaves the slot's new records in LDS (each output record reuses the LDS cell of an
+    // input record of the SAME slot, which only this lane read: no hazard), and after one barrier the slots' own lanes store them
+    // coalesced.  Permuted lanes storing straight to the pool write partial 128-B lines from several waves: measured 1.5x (class
+    // sorted) to 2.3x (interleaved) longer launches.  Cells: beta, L, ray_d, ray_o, nee, ids in place; sh_d in s_hit; the "which
+    // records changed" flags travel in bits 1.. of ray_d.w (bit 0 = an extend ray is pending, what the trace kernel looks at).
+    // 28 KB of cells + 3 KB of tables: three shade blocks and one 64-KB trace block fit a CU's 160 KB together.
+#define OUT_RAY_O 2u
+#define OUT_SHADOW 4u
+#define OUT_IDS 8u
+    __shared__ uint32_t s_perm[MCPT_BLOCK];
+    __shared__ uint32_t s_kcnt[K_COUNT * (MCPT_BLOCK / 64)];                   // [key][wave]: count, then exclusive prefix
     // Small scene tables staged in LDS once per block: every scattered global load costs vector-memory issue time whether its
-    // lanes hit 2 distinct lines or 64, and shade was bound by ~25 of them per wave.  Lights (record + fp64 corners) and
-    // materials are tiny in typical scenes; larger tables fall back to global memory.
+    // lanes hit 2 distinct lines or 64.  Lights (record + fp64 corners) and materials are tiny in typical scenes; larger tables
+    // fall back to global memory.
     __shared__ float4 s_mats[WF_LDS_MATS * 4];
     __shared__ float4 s_lights[WF_LDS_LIGHTS * 4];
     __shared__ double s_light_pos[WF_LDS_LIGHTS * 9];
     const bool mats_lds = sc.n_mats <= WF_LDS_MATS, lights_lds = sc.n_lights <= WF_LDS_LIGHTS;
-    if (mats_lds) for (uint32_t i = threadIdx.x; i < (uint32_t)sc.n_mats * 4; i += MCPT_BLOCK) s_mats[i] = reinterpret_cast<const float4*>(sc.mats)[i];
+    if (mats_lds) for (uint32_t i = tid; i < (uint32_t)sc.n_mats * 4; i += MCPT_BLOCK) s_mats[i] = reinterpret_cast<const float4*>(sc.mats)[i];
     if (lights_lds) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.n_lights * 4; i += MCPT_BLOCK) s_lights[i] = reinterpret_cast<const float4*>(sc.lights)[i];
-        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.n_lights * 9; i += MCPT_BLOCK) s_light_pos[i] = sc.tri_pos64[9 * (size_t)sc.lights[i / 9].tri + i % 9];
+        for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 4; i += MCPT_BLOCK) s_lights[i] = reinterpret_cast<const float4*>(sc.lights)[i];
+        for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 9; i += MCPT_BLOCK) s_light_pos[i] = sc.tri_pos64[9 * (size_t)sc.lights[i / 9].tri + i % 9];
     }
-    __syncthreads();
 
-    const float4 bt = ld_s(&pool.beta[slot]);
-    const uint32_t st = __float_as_uint(bt.w);
+    // ---- classification of the lane's OWN slot (coalesced): which branch will this slot take?
+    {
+        const float4 bt0 = ld_s(&pool.beta[base + tid]), h0 = ld_s(&pool.hit[base + tid]);
+        const uint4 id0 = ld_s(&pool.ids[base + tid]);
+        s_L[tid] = ld_s(&pool.L[base + tid]); s_rd[tid] = ld_s(&pool.ray_d[base + tid]); s_nee[tid] = ld_s(&pool.nee[base + tid]);
+        s_ro[tid] = ld_s(&pool.ray_o[base + tid]);
+        s_beta[tid] = bt0; s_hit[tid] = h0; s_ids[tid] = id0;
+        const uint32_t st0 = __float_as_uint(bt0.w);
+        const int bounce0 = (int)(st0 >> 8), tri0 = __float_as_int(h0.x);
+        uint32_t key = K_END;
+        if ((st0 & 3u) == SLOT_ALIVE && tri0 >= 0) {
+            bool ends = p.max_depth != 0 && (uint32_t)bounce0 >= p.max_depth;                       // `bounces < max_depth` (Render.cpp:116)
+            if (bounce0 - 1 > 3) {                                                                 // Render.cpp:164-168
+                const float q = fminf(max3(xyz(bt0)), 0.95f);
+                const Rng4 r = rng_block(id0.x, id0.y, 2u + 2u * (uint32_t)(bounce0 - 1), p.seed_lo, p.seed_hi);
+                ends = ends || r.v[2] > q;
+            }
+            key = ends ? K_EMIT : K_DIFF + ((uint32_t)tri0 >> HIT_CLASS_SHIFT);
+        }
+#ifdef MCPT_SHADE_NOSORT                                                                           // A/B build: slot order, same code otherwise
+        const uint32_t skey = 0;
+#else
+        const uint32_t skey = key;
+#endif
+        uint32_t my_rank = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < K_COUNT; k++) {
+            const uint64_t m = __ballot(skey == k);
+            if (skey == k) my_rank = lane_rank(m);
+            if (lane == k) s_kcnt[k * (MCPT_BLOCK / 64) + wv] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < K_COUNT * (MCPT_BLOCK / 64); i++) { const uint32_t c = s_kcnt[i]; s_kcnt[i] = run; run += c; } }
+        __syncthreads();
+        s_perm[s_kcnt[skey * (MCPT_BLOCK / 64) + wv] + my_rank] = tid | (key << 16);
+        __syncthreads();
+    }
+#ifdef MCPT_SHADE_PERM_TEST     // diagnostic: a class-blind interleave -- every wave touches every line of the window, no sorting benefit
+    const uint32_t pk = s_perm[((tid & 63u) << 2) | (tid >> 6)];
+#else
+    const uint32_t pk = s_perm[tid];
+#endif
+    const uint32_t key = pk >> 16, src = pk & 0xffffu, slot = base + src;
+
+    // From here on the slot's LDS cells are the HOME of its state: values are read where a phase needs them and parked again when it is
+    // done (the cells belong to this lane alone), so that almost nothing but indices stays in registers across the register-hungry
+    // fp64 light-sampling phase.  WF_PHASE() is a compiler-only fence: it keeps the scheduler from hoisting the next phase's LDS reads
+    // (and their destination registers) up into the previous one.
+#define WF_PHASE() asm volatile("" ::: "memory")
+    const uint32_t st = __float_as_uint(s_beta[src].w);
     uint32_t state = st & 3u;
     bool prev_mirror = (st & 4u) != 0;
     int bounce = (int)(st >> 8);
-    f3 beta = xyz(bt);
-    const float4 Lp = ld_s(&pool.L[slot]);
-    f3 L = xyz(Lp);
-    float prev_pdf = Lp.w;
-    uint4 id = ld_s(&pool.ids[slot]);                                              // pixel, sample, s_next, s_end
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f); bool sm_loaded = false;    // item accumulator: fetched only when a path ends
-    // one batch of requests for everything an ALIVE slot needs about its traced ray (nearly every slot is ALIVE in steady state)
-    // (requested unconditionally so they go out in the same batch as beta / L / ids: one memory round trip for all slot state)
-    const float4 h = ld_s(&pool.hit[slot]), rd4 = ld_s(&pool.ray_d[slot]); const double4 og = ld_s(&pool.org64[slot]);
     const float nl = (float)sc.n_lights;
     const bool correct_t2 = (p.flags & MCPT_FLAG_CORRECT_SHADOW_T2) != 0;
 
     bool terminated = false, emit_extend = false, emit_shadow = false, sum_dirty = false, id_dirty = false;
     bool c_prim = false, c_cont = false, c_self_t = false, c_self_h = false, c_shaded = false;
     uint32_t c_texel = 0;
-    f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
-    int sh_skip = -1;
+    uint32_t out_flags = 0;
 
-#ifdef MCPT_EXPERIMENT_SHADE_NULL     // timing diagnostic: slot-state streaming + regeneration only, no hit processing (image is garbage)
-    if (state == SLOT_ALIVE) {
-        if (bounce >= 3 || __float_as_int(h.x) < 0) terminated = true;
-        else { no = mk3((float)og.x, (float)og.y, (float)og.z); nd = xyz(rd4); bounce++; emit_extend = true; c_cont = true; }
-    } else if (state == SLOT_DRAIN) terminated = true;
-    if (false) do {
-        const int tri = -1;
-#else
-    if (state == SLOT_ALIVE) do {
-        const int tri = __float_as_int(h.x);
-#endif
-        if (tri < 0) { terminated = true; break; }                                             // Render.cpp:118-119,144-145
-        float hu, hv;
-        const f3 d = xyz(rd4);
-        // second batch: the light record + its fp64 corners are requested NOW (they depend only on the RNG key), together with
-        // the hit triangle's fp64 corners and shading record below -- one memory round trip instead of two
-        const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
-        hu = h.y; hv = h.z;                                                                      // fp32 barycentrics of the traversal
-        const d3 p64 = hit_point64_plane(sc, tri, mkd(og.x, og.y, og.z), d);                    // og = fp64 origin of the traced ray
-        const f3 p32 = to_f3(p64);
-        // Light sample first (Render.cpp:124 draws it before anything else uses it): its fp64 temporaries are dead before the
-        // BSDF state below comes alive -- keeps the kernel under the next VGPR occupancy step.
-        LightSample ls;
+    if (state != SLOT_DEAD && (st & 8u) != 0) {                                        // Render.cpp:125-130: the previous vertex's light sample
+        const float4 n4 = s_nee[src];                                                  // (.w != 0: the trace kernel found the shadow ray blocked)
+        if (__float_as_uint(n4.w) == 0u) { float4 L4 = s_L[src]; L4.x += n4.x; L4.y += n4.y; L4.z += n4.z; s_L[src] = L4; }
+    }
+    if (key != K_END) do {                                                             // ALIVE and the extend ray hit something
+        int tri;
+        {   // ---- phase 1: the hit record (Triangle.cpp:68-76), emitter MIS (Render.cpp:146-162), roulette rescale, first-hit emission
+            const float4 h = s_hit[src];
+            tri = __float_as_int(h.x) & HIT_TRI_MASK;
+            const f3 d = xyz(s_rd[src]);
+            const HitShade hs = load_hit_shade(sc, tri, h.y, h.z, d);                            // h.y, h.z: fp32 barycentrics of the traversal
+            const float4 m1 = mats_lds ? s_mats[4 * hs.mat + 1] : reinterpret_cast<const float4*>(sc.mats)[4 * hs.mat + 1];   // radiance | flags
+            const uint32_t mflags = __float_as_uint(m1.w);
+            c_shaded = true;
+            if (bounce > 0 && (mflags & MAT_EMISSIVE) && hs.front) {                            // Render.cpp:146-162
+                const f3 rad = xyz(m1), beta = xyz(s_beta[src]);
+                float4 L4 = s_L[src];
+                f3 add;
+                if (prev_mirror) add = beta * rad;
+                else {
+                    // Render.cpp:150-152 measures |prev - p| and the cosine along normalize(prev - p): the traced ray IS that segment
+                    // (unit direction d, hit distance h.w), so neither the previous vertex nor a square root is needed
+                    const float cosine = -dot(d, hs.n);
+                    float light_pdf = 0.f;
+                    if (cosine != 0.f) light_pdf = h.w * h.w * rcp(cosine * nl * tri_area(sc, tri));
+                    add = beta * rad * power_heuristic(L4.w, light_pdf);                        // L4.w = pdf of the BSDF sample that got here
+                }
+                L4.x += add.x; L4.y += add.y; L4.z += add.z;
+                s_L[src] = L4;
+            }
+            if (key == K_EMIT) { terminated = true; break; }                                    // Render.cpp:164-170 / `bounces < max_depth`
+            if (bounce - 1 > 3) {                                                               // survived the roulette (decided above)
+                float4 b4 = s_beta[src];
+                const float iq = rcp(fminf(fmaxf(fmaxf(b4.x, b4.y), b4.z), 0.95f));
+                b4.x *= iq; b4.y *= iq; b4.z *= iq;
+                s_beta[src] = b4;
+            }
+            if (bounce == 0 && (mflags & MAT_EMIT_0)) { float4 L4 = s_L[src]; L4.x += m1.x; L4.y += m1.y; L4.z += m1.z; s_L[src] = L4; }   // :121-122
+            // park what the BSDF phase needs of the hit record in the two cells this slot no longer needs (hit, NEE payload)
+            s_hit[src] = mk4(hs.n, hs.tu); s_nee[src] = make_float4(hs.tv, __int_as_float(hs.mat), 0.f, 0.f);
+        }
+        WF_PHASE();
+        // ---- phase 2: light sample (Render.cpp:124, :202-223) with the fp64 self-hit predicate of SURVEY A-9
+        // The hit point in fp64: ray (fp32 origin the trace kernel used, fp32 direction) x the triangle's fp64 plane.  Like the
+        // reference's point (Triangle.cpp:35-38) it lies on that plane to ~1e-16 with full fp64 noise in its low bits -- the two
+        // properties the self-occlusion statistics of SURVEY A-9 rest on; where exactly on the plane moves by ~1e-8 with the origin's
+        // rounding, which no statistic sees (r01 carried a 32-B fp64 origin per slot for this: 64 B of pool traffic per bounce).
+        LightSample ls; f3 p32; float xi_lobe;
         {
+            const uint4 id = s_ids[src];
+            const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
+            xi_lobe = ra.v[3];
+            const d3 p64 = hit_point64_plane(sc, tri, to_d3(xyz(s_ro[src])), xyz(s_rd[src]));
+            p32 = to_f3(p64);
             LightData ld;
             if (lights_lds) {
                 const int cnt = sc.n_lights;
@@ -139,74 +243,62 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
             } else ld = light_fetch(sc, ra.v[0]);
             ls = sample_light(ld, p64, ra.v[1], ra.v[2], true);
         }
-        const HitShade hs = load_hit_shade(sc, tri, hu, hv, d);
-        DevMaterial mat;
-        if (mats_lds) { float4* m4 = reinterpret_cast<float4*>(&mat); m4[0] = s_mats[4 * hs.mat]; m4[1] = s_mats[4 * hs.mat + 1]; m4[2] = s_mats[4 * hs.mat + 2]; m4[3] = s_mats[4 * hs.mat + 3]; }
-        else mat = sc.mats[hs.mat];
-        c_shaded = true;
-        if (bounce > 0) {
-            if ((mat.flags & MAT_EMISSIVE) && hs.front) {                                       // Render.cpp:146-162
-                const f3 rad = mk3(mat.radiance[0], mat.radiance[1], mat.radiance[2]);
-                if (prev_mirror) L = L + beta * rad;
-                else {
-                    // Render.cpp:150-152 measures |prev - p| and the cosine along normalize(prev - p): the traced ray IS that segment
-                    // (unit direction d, hit distance h.w), so neither the previous vertex nor a square root is needed
-                    const float len = h.w;
-                    const float cosine = -dot(d, hs.n);
-                    float light_pdf = 0.f;
-                    if (cosine != 0.f) light_pdf = len * len * rcp(cosine * nl * tri_area(sc, tri));
-                    L = L + beta * rad * power_heuristic(prev_pdf, light_pdf);
-                }
-            }
-            if (bounce - 1 > 3) {                                                              // Render.cpp:164-170
-                const float q = fminf(max3(beta), 0.95f);
-                const Rng4 r = rng_block(id.x, id.y, 2u + 2u * (uint32_t)(bounce - 1), p.seed_lo, p.seed_hi);
-                if (r.v[2] > q) { terminated = true; break; }
-                beta = beta / q;
-            }
+        WF_PHASE();
+        // ---- phase 3: BSDF (BSDF.cpp:87-110), NEE with MIS (Render.cpp:125-130), BSDF sample (Render.cpp:133-140)
+        Bsdf bsdf;
+        {
+            const float4 hn = s_hit[src], ht = s_nee[src];
+            const int mi = __float_as_int(ht.y);
+            DevMaterial mat;
+            if (mats_lds) { float4* m4 = reinterpret_cast<float4*>(&mat); m4[0] = s_mats[4 * mi]; m4[1] = s_mats[4 * mi + 1]; m4[2] = s_mats[4 * mi + 2]; m4[3] = s_mats[4 * mi + 3]; }
+            else mat = sc.mats[mi];
+            const f3 kd = tex_color(sc, mat, hn.w, ht.x, c_texel);
+            bsdf = make_bsdf(mat, kd, xyz(hn), -xyz(s_rd[src]));
         }
-        if (p.max_depth != 0 && (uint32_t)bounce >= p.max_depth) { terminated = true; break; }  // `bounces < max_depth`
-        if (bounce == 0 && (mat.flags & MAT_EMIT_0)) L = L + mk3(mat.radiance[0], mat.radiance[1], mat.radiance[2]);   // :121-122
-
-        const f3 kd = tex_color(sc, mat, hs.tu, hs.tv, c_texel);
-        const Bsdf bsdf = make_bsdf(mat, kd, hs.n, -d);
-        const Rng4 rb = rng_block(id.x, id.y, 2u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
+        int sh_skip = -1;
         if (ls.pdf != 0.f) {
             c_self_t = true; c_self_h = ls.self_hit;
             if (correct_t2 || !ls.self_hit) {
                 f3 fx; float bpdf;
                 bsdf_eval(bsdf, ls.wo, fx, bpdf);
-                const float cos_theta = fabsf(dot(hs.n, ls.wo));
+                const float cos_theta = fabsf(dot(bsdf.w, ls.wo));
                 const float weight = power_heuristic(ls.pdf * rcp(nl), bpdf);
-                const f3 nee = weight * beta * ls.rad * fx * (cos_theta * rcp(ls.pdf) * nl);        // Render.cpp:127-129
-                // the shadow ray's payload is final here: store it now rather than carrying 8 registers through bsdf_sample
-                st_s(&pool.sh_d[slot], mk4(ls.wo, ls.t2)); st_s(&pool.nee[slot], mk4(nee, 0.f));
+                const f3 nee = weight * xyz(s_beta[src]) * ls.rad * fx * (cos_theta * rcp(ls.pdf) * nl);   // Render.cpp:127-129
+                s_hit[src] = mk4(ls.wo, ls.t2); s_nee[src] = mk4(nee, 0.f); out_flags |= OUT_SHADOW;   // the shadow ray: sh_d cell, NEE payload
                 sh_skip = ls.tri; emit_shadow = true;
             }
         }
-        no = p32;                                                                               // both new rays start at the hit point
-        st_s(&pool.org64[slot], make_double4(p64.x, p64.y, p64.z, 0.0));                        // (stored now: frees 6 registers; a path that
-                                                                                                //  ends below simply leaves it unused)
-        const Scatter s = bsdf_sample(bsdf, ra.v[3], rb.v[0], rb.v[1]);                         // Render.cpp:133-134
+        s_ro[src] = mk4(p32, __int_as_float(sh_skip)); out_flags |= OUT_RAY_O;                  // both new rays start at the hit point
+        Scatter s;
+        {
+            const uint4 id = s_ids[src];
+            const Rng4 rb = rng_block(id.x, id.y, 2u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
+            s = bsdf_sample(bsdf, xi_lobe, rb.v[0], rb.v[1]);                                   // Render.cpp:133-134
+        }
         if (s.pdf == 0.f) {                                                                     // Render.cpp:135-136: path ends, but its last
             state = SLOT_DRAIN;                                                                 // shadow ray is still in flight -> finalise next call
             break;
         }
-        const float cos_theta = fabsf(dot(hs.n, s.wo));
-        beta = beta * (s.f * (cos_theta * rcp(s.pdf)));                                         // Render.cpp:140
-        prev_pdf = s.pdf; prev_mirror = s.mirror;
-        nd = s.wo; bounce++;
+        {
+            const float sc_ = fabsf(dot(bsdf.w, s.wo)) * rcp(s.pdf);
+            float4 b4 = s_beta[src];
+            b4.x *= s.f.x * sc_; b4.y *= s.f.y * sc_; b4.z *= s.f.z * sc_;                      // Render.cpp:140
+            s_beta[src] = b4;
+            float4 L4 = s_L[src]; L4.w = s.pdf; s_L[src] = L4;
+        }
+        prev_mirror = s.mirror;
+        s_rd[src] = mk4(s.wo, 0.f); bounce++;
         emit_extend = true; c_cont = true;
     } while (0);
-#ifndef MCPT_EXPERIMENT_SHADE_NULL
-    else if (state == SLOT_DRAIN) terminated = true;
-#endif
+    else if (state != SLOT_DEAD) terminated = true;                                             // miss (Render.cpp:118-119,144-145) or DRAIN
+    WF_PHASE();
+    uint4 id = s_ids[src];                                                                      // pixel, sample, s_next, s_end
 
     // one-sample items (the default) flush every finished sample straight to the film: their accumulator record is always zero, so
     // it is neither fetched (a dependent round trip in front of the regeneration) nor written back
     if (p.samples_per_item != 1u && (terminated || (state == SLOT_DEAD && id.z == id.w))) { sm = ld_s(&pool.sum[slot]); sm_loaded = true; }
     if (terminated) {                                                                           // Scene::set_Pixel, per sample
-        const f3 c = wf_scrub_nan(L);
+        const f3 c = wf_scrub_nan(xyz(s_L[src]));
         sm.x += c.x; sm.y += c.y; sm.z += c.z; sm.w += 1.f; sum_dirty = true;
         state = SLOT_DEAD;
     }
@@ -223,39 +315,38 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     // ---- pull new work items: one atomic per BLOCK on one of WF_ITEM_SHARDS cursors (own shard first, then a few others);
     //      a plain load screens out exhausted shards so the end-of-render tail costs no atomics at all
     {
-        const uint32_t wv_ = threadIdx.x >> 6;
         const uint64_t m = __ballot(want_item);
-        if (lane == 0) s_wave_cnt[wv_] = (uint32_t)__popcll(m);
+        if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(m);
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             uint32_t tot = 0; for (uint32_t k = 0; k < MCPT_BLOCK / 64; k++) tot += s_wave_cnt[k];
-            uint32_t base = 0xffffffffu, sel = 0;
+            uint32_t b0 = 0xffffffffu, sel = 0;
             if (tot) {
                 for (uint32_t probe = 0; probe < 4; probe++) {
                     const uint32_t k = (blockIdx.x + probe * 17u) & (WF_ITEM_SHARDS - 1);
                     const uint32_t cap = wf_shard_capacity(n_items, k);
                     if (__hip_atomic_load(&ctl->item_cursor[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cap) {
                         const uint32_t b = atomicAdd(&ctl->item_cursor[k].v, tot);
-                        if (b < cap) { base = b; sel = k; break; }
+                        if (b < cap) { b0 = b; sel = k; break; }
                     }
                 }
             }
-            s_base = base; s_sel = sel;
+            s_base = b0; s_sel = sel;
         }
         __syncthreads();
         if (want_item) {
             id.z = id.w = 0; id_dirty = true;
             if (s_base != 0xffffffffu) {
                 uint32_t before = 0;
-                for (uint32_t k = 0; k < wv_; k++) before += s_wave_cnt[k];
+                for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
                 const uint32_t l = s_base + before + lane_rank(m);
                 const uint32_t item = ((l / MCPT_BLOCK) * WF_ITEM_SHARDS + s_sel) * MCPT_BLOCK + (l % MCPT_BLOCK);
                 if (p.probe_n) {                                            // probe: item = film entry, one sample
                     if (item < p.probe_n) { id.x = item; id.z = p.first_sample; id.w = p.first_sample + 1u; }
                 } else if (item < n_items) {
                     const uint32_t n_tiles = p.tiles_x * p.tiles_y;
-                    const uint32_t wv = item >> 6, il = item & 63u;
-                    const uint32_t chunk = wv / n_tiles, tile = wv - chunk * n_tiles;
+                    const uint32_t iw = item >> 6, il = item & 63u;
+                    const uint32_t chunk = iw / n_tiles, tile = iw - chunk * n_tiles;
                     const uint32_t px = (tile % p.tiles_x) * 8 + (il & 7), py = (tile / p.tiles_x) * 8 + (il >> 3);
                     if (px < (uint32_t)sc.cam.width && py < (uint32_t)sc.cam.height) {
                         id.x = py * (uint32_t)sc.cam.width + px;
@@ -269,39 +360,55 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     }
     if (state == SLOT_DEAD && id.z < id.w) {                                                    // next sample of the item: camera ray
         id.y = id.z++; id_dirty = true;
-        const Rng4 r = rng_block(id.x, id.y, 0u, p.seed_lo, p.seed_hi);
-        const int px = (int)(id.x % (uint32_t)sc.cam.width), py = (int)(id.x / (uint32_t)sc.cam.width);
-        d3 eye64;
+        d3 eye64; f3 no, nd;                                                                    // (the fp32 origin `no` is what travels)
         if (p.probe_n) {                                                                        // mcpt_probe_paths: the caller's ray
             eye64 = mkd(p.probe_o[3 * id.x], p.probe_o[3 * id.x + 1], p.probe_o[3 * id.x + 2]); no = to_f3(eye64);
             nd = mk3((float)p.probe_d[3 * id.x], (float)p.probe_d[3 * id.x + 1], (float)p.probe_d[3 * id.x + 2]);
-        } else
-        cast_ray(sc.cam, px, py, r.v[0], r.v[1], eye64, no, nd);                                // Render.cpp:64
-        st_s(&pool.org64[slot], make_double4(eye64.x, eye64.y, eye64.z, 0.0));
-        beta = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f); bounce = 0; prev_pdf = 0.f; prev_mirror = false;
+        } else {
+            const Rng4 r = rng_block(id.x, id.y, 0u, p.seed_lo, p.seed_hi);
+            const int px = (int)(id.x % (uint32_t)sc.cam.width), py = (int)(id.x / (uint32_t)sc.cam.width);
+            cast_ray(sc.cam, px, py, r.v[0], r.v[1], eye64, no, nd);                            // Render.cpp:64
+        }
+        s_ro[src] = mk4(no, __int_as_float(-1)); out_flags |= OUT_RAY_O;
+        s_rd[src] = mk4(nd, 0.f);
+        s_beta[src] = make_float4(1.f, 1.f, 1.f, 0.f); s_L[src] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bounce = 0; prev_mirror = false;
         state = SLOT_ALIVE; emit_extend = true; c_prim = true;
     }
 
-    // ---- write the slot back
-    st_s(&pool.beta[slot], mk4(beta, __uint_as_float(state | (prev_mirror ? 4u : 0u) | ((uint32_t)bounce << 8))));
-    st_s(&pool.L[slot], mk4(L, prev_pdf));
-    if (emit_extend || emit_shadow) st_s(&pool.ray_o[slot], mk4(no, __int_as_float(sh_skip)));
-    st_s(&pool.ray_d[slot], mk4(nd, emit_extend ? 1.f : 0.f));
-    if (sum_dirty && sm_loaded) st_s(&pool.sum[slot], sm);
-    if (id_dirty) st_s(&pool.ids[slot], id);
+    // ---- finish the slot's cells: state word, "which records changed" flags
+    {
+        float4 b4 = s_beta[src];
+        b4.w = __uint_as_float(state | (prev_mirror ? 4u : 0u) | (emit_shadow ? 8u : 0u) | ((uint32_t)bounce << 8));
+        s_beta[src] = b4;
+        if (sum_dirty && sm_loaded) st_s(&pool.sum[slot], sm);                   // multi-sample items only (not the default): stored directly
+        if (id_dirty) { s_ids[src] = id; out_flags |= OUT_IDS; }
+        float4 r4 = s_rd[src];
+        r4.w = __uint_as_float(out_flags | (emit_extend ? 1u : 0u));
+        s_rd[src] = r4;
+    }
 
     // ---- shadow queue append, atomic-free: ranks inside the block through LDS; the block owns queue entries [256 b, 256 b + n) and
     //      publishes n with a plain store.  (A returning atomic per block on a shared cursor -- even sharded 8 ways -- held every
     //      block's four waves at the barrier for its round trip: 0.58 vs 0.24 ms per launch.)
-    const uint32_t cur = it & 3, wv = threadIdx.x >> 6;
+    const uint32_t cur = it & 3;
     const uint64_t ms = __ballot(emit_shadow);
     if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(ms);
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t tot = 0; for (uint32_t k = 0; k < MCPT_BLOCK / 64; k++) tot += s_wave_cnt[k]; st_s(&pool.shadow_count[blockIdx.x], tot); }
+    if (tid == 0) { uint32_t tot = 0; for (uint32_t k = 0; k < MCPT_BLOCK / 64; k++) tot += s_wave_cnt[k]; st_s(&pool.shadow_count[blockIdx.x], tot); }
     if (emit_shadow) {
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
-        st_s(&pool.shadow_queue[blockIdx.x * MCPT_BLOCK + before + lane_rank(ms)], slot);
+        st_s(&pool.shadow_queue[base + before + lane_rank(ms)], slot);
+    }
+    {   // the barrier above also published every slot's output cells: store the OWN slot's records, coalesced
+        const uint32_t own = base + tid;
+        const float4 rdo = s_rd[tid];
+        const uint32_t fl = __float_as_uint(rdo.w);
+        st_s(&pool.beta[own], s_beta[tid]); st_s(&pool.L[own], s_L[tid]); st_s(&pool.ray_d[own], rdo);
+        if (fl & OUT_RAY_O) st_s(&pool.ray_o[own], s_ro[tid]);
+        if (fl & OUT_SHADOW) { st_s(&pool.sh_d[own], s_hit[tid]); st_s(&pool.nee[own], s_nee[tid]); }
+        if (fl & OUT_IDS) st_s(&pool.ids[own], s_ids[tid]);
     }
     // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
     const uint64_t ma = __ballot(state != SLOT_DEAD);
@@ -397,10 +504,14 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     float idx = 0, idy = 0, idz = 0, oodx = 0, oody = 0, oodz = 0, tmax = 0;
     int node = MCPT_NODE_SENTINEL, sp = 1;
-    int htri = -1; float ht = 0, hu = 0, hv = 0;
+    int htri = -1; float hu = 0, hv = 0;
     uint32_t n_box = 0, n_tri = 0, n_spill = 0;     // n_spill: stack entries that went to the global overflow area (COUNT builds)
 #ifdef WF_SCHED_STATS
     uint32_t x_inner = 0, x_leaf = 0, x_refill = 0, l_refill = 0;    // block executions (wave-uniform); n_box / n_tri count lane participations
+    unsigned long long t_inner = 0, t_leaf = 0, t_refill = 0, t_mark = __builtin_amdgcn_s_memtime();   // shader cycles spent in each block type
+#define WF_TICK(acc) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc += t_now - t_mark; t_mark = t_now; }
+#else
+#define WF_TICK(acc)
 #endif
     const bool greedy = tune.policy == 1;
 
@@ -417,14 +528,10 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
             x_refill++; l_refill += (uint32_t)n_idle;
 #endif
             if (have && node == MCPT_NODE_SENTINEL) {                    // finished: write the result back
-                if (any) {
-                    if (!blocked) {                                      // Render.cpp:125-130: unoccluded -> L += NEE term
-                        const float4 n4 = ld_s(&pool.nee[slot]); float4 l4 = ld_s(&pool.L[slot]);
-                        l4.x += n4.x; l4.y += n4.y; l4.z += n4.z;
-                        st_s(&pool.L[slot], l4);
-                    }
+                if (any) {                                               // Render.cpp:125-130: the verdict.  The next shade call adds the
+                    if (blocked) st_s(reinterpret_cast<uint32_t*>(&pool.nee[slot]) + 3, 1u);   // ... NEE term it parked in pool.nee unless .w says "blocked"
                 } else {
-                    st_s(&pool.hit[slot], make_float4(__int_as_float(htri), hu, hv, ht));
+                    st_s(&pool.hit[slot], make_float4(__int_as_float(htri), hu, hv, tmax));   // closest hit: tmax IS its distance
                 }
                 have = false;
             }
@@ -453,7 +560,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     if (!my_shadow) {                                    // extend ray of slot my_w
                         slot = my_w;
                         const float4 rd = ld_s(&pool.ray_d[my_w]);
-                        valid = rd.w != 0.f;
+                        valid = (__float_as_uint(rd.w) & 1u) != 0u;
                         const float4 ro = ld_s(&pool.ray_o[my_w]);
                         o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; skip = -1;
                     } else {                                             // shadow ray of a queued slot
@@ -468,11 +575,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                         idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
                         oodx = o.x * idx; oody = o.y * idy; oodz = o.z * idz;
                         stk[0] = MCPT_NODE_SENTINEL; sp = 1; node = 0;
-                        htri = -1; ht = 0.f; hu = 0.f; hv = 0.f; blocked = false;
+                        htri = -1; hu = 0.f; hv = 0.f; blocked = false;
                         have = true;
                     }
                 }
             }
+            WF_TICK(t_refill)
             if (exhausted && __ballot(have) == 0) break;
             continue;
         }
@@ -498,12 +606,13 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     if (any) {                                           // Triangle::isIntersect
                         if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; }
                     } else {                                             // Triangle::hit
-                        if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ti; ht = r.t; hu = r.u; hv = r.v; }
+                        if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ti | __float_as_int(v0.w); hu = r.u; hv = r.v; }   // v0.w = lobe class << 28
                     }
                 }
                 if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
                 else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
             }
+            WF_TICK(t_leaf)
             continue;
         }
 
@@ -576,6 +685,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                 keep = (cl > cf ? cl : cf) + 1;
             }
         } while (__popcll(__ballot(have && node >= 0)) >= keep);
+        WF_TICK(t_inner)
     }
 
     if (COUNT) {
@@ -588,6 +698,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
             atomicAdd(&g->paths, wall_clock64() - t_start);            // wave lifetime in 10-ns ticks
             atomicAdd(&g->shaded_hits, (unsigned long long)x_inner); atomicAdd(&g->texel_fetches, (unsigned long long)x_leaf);
             atomicAdd(&g->self_shadow_tests, (unsigned long long)x_refill); atomicAdd(&g->self_shadow_hits, (unsigned long long)l_refill);
+            atomicAdd(&g->debug[0], t_inner); atomicAdd(&g->debug[1], t_leaf); atomicAdd(&g->debug[2], t_refill);
 #endif
         }
     }

@@ -18,3 +18,7 @@ grid = int(os.environ.get("MCPT_WF_GRID", "192"))
 waves = grid * 16
 print("trace launches %d, mean launch %.3f ms; mean wave lifetime %.3f ms = %.1f %% of the launch (grid %d blocks assumed)" % (
     c.iterations, c.trace_ms_total / c.iterations, c.paths * 1e-5 / (c.iterations * waves), 100.0 * c.paths * 1e-5 / (waves * c.trace_ms_total), grid), flush=True)
+tot = float(sum(c.debug[:3])) or 1.0
+print("wave time by scheduler block (shader cycles, s_memtime): inner %.1f %%  leaf %.1f %%  refill %.1f %%   | cycles per execution: inner %.0f  leaf %.0f  refill %.0f" % (
+    100 * c.debug[0] / tot, 100 * c.debug[1] / tot, 100 * c.debug[2] / tot, c.debug[0] / max(1, c.shaded_hits), c.debug[1] / max(1, c.texel_fetches),
+    c.debug[2] / max(1, c.self_shadow_tests)), flush=True)
