@@ -225,23 +225,24 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             if (o.flags & MCPT_FLAG_DETERMINISTIC) n_lanes = 1;          // one owner per pixel, plain stores
             // Persistent trace grid.  One sub-pipeline: fill every CU (2 blocks = 32 waves).  Two: the trace of one runs beside the
             // shade (or trace) of the other.  While the traversal data (4-wide nodes + triangle records) is cache-resident the pair is
-            // fastest with ~12 trace waves per CU -- grid = 3/4 of the CUs: 594 vs 617 ms at 1/CU and 662 ms at 2/CU on the bench
-            // workload (3.3 MB), 629 vs 646 ms at 7.7 MB -- the rest of each CU's wave slots go to shade.  Once it spills out of L2
+            // fastest with ~14 trace waves per CU -- grid = 7/8 of the CUs (r02, 72-register trace beside the 104-register sorted shade:
+            // 485 / 478 / 466 / 474 ms at 160 / 192 / 224 / 256 blocks on the bench workload; r01's 132-register shade wanted 3/4) --
+            // the rest of each CU's registers go to shade waves.  Once it spills out of L2
             // the trace kernel is the longer pole and wants every slot: 345 vs 366 ms at 48 MB, 838 vs 904 ms at 350 MB.
             const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0));
             const size_t traversal_bytes = hs.nodes4.size() * sizeof(f4h) + hs.tri_isect.size() * sizeof(f4h);
             const bool cache_resident = traversal_bytes <= (size_t(16) << 20);
-            c->trace_grid = (n_lanes > 1 && cache_resident) ? std::max(1u, uint32_t(c->n_cus) * 3u / 4u) : uint32_t(c->n_cus) * per_cu;
+            c->trace_grid = (n_lanes > 1 && cache_resident) ? std::max(1u, uint32_t(c->n_cus) * 7u / 8u) : uint32_t(c->n_cus) * per_cu;
             c->trace_grid = std::min(env_u32("MCPT_WF_GRID", c->trace_grid), uint32_t(c->n_cus) * per_cu);
             if ((e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
             c->lanes.resize(n_lanes);
             for (auto& L : c->lanes) {
                 L.pool.P = P;
-                L.pool_bufs.resize(11);
-                void** dst[11] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sh_d, (void**)&L.pool.nee,
+                L.pool_bufs.resize(12);
+                void** dst[12] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sq_d, (void**)&L.pool.nee,
                                   (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
-                                  (void**)&L.pool.shadow_count};
-                for (int i = 0; i < 11; i++) {
+                                  (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o};
+                for (int i = 0; i < 12; i++) {
                     const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * 16;
                     if ((e = L.pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
                     if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
@@ -613,7 +614,7 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(pool.ray_o, ro.data(), ro.size() * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(pool.ray_d, rd.data(), rd.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(pool.sh_d, sd.data(), sd.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pool.sq_d, sd.data(), sd.size() * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(pool.sq_o, ro.data(), ro.size() * 4, hipMemcpyHostToDevice));   // queue entry i = slot i
     HIP_TRY(hipMemset(pool.hit, 0xff, size_t(P) * 16));
     HIP_TRY(hipMemset(pool.nee, 0, size_t(P) * 16));                 // nee.w == 0 afterwards <=> the trace kernel did not flag the ray as blocked
     HIP_TRY(hipMemcpy(pool.shadow_queue, queue.data(), queue.size() * 4, hipMemcpyHostToDevice));

@@ -422,7 +422,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     for (uint32_t i = 0; i < nf; i++) pos_of_face[order[i]] = int(i);
 
     // ---- streams in leaf order
-    out.tri_isect.resize(3 * size_t(nf)); out.tri_shade.resize(4 * size_t(nf)); out.tri_pos64.resize(9 * size_t(nf)); out.tri_plane64.resize(4 * size_t(nf)); out.tri_face.resize(nf);
+    out.tri_isect.assign(3 * size_t(nf) + 3, f4h{0.f, 0.f, 0.f, 0.f});    /* + one spare record: the trace kernel fetches triangles in pairs */ out.tri_shade.resize(4 * size_t(nf)); out.tri_pos64.resize(9 * size_t(nf)); out.tri_plane64.resize(4 * size_t(nf)); out.tri_face.resize(nf);
     parallel_for(nf, [&](uint32_t i_begin, uint32_t i_end) {
     for (uint32_t i = i_begin; i < i_end; i++) {
         const int f = order[i];

@@ -11,10 +11,11 @@
 #define SLOT_DRAIN 2u   // path ended in the same shade call that emitted its last shadow ray: finalise next call
 
 struct PathPool {
-    float4* ray_o;      // extend-ray origin xyz (= previous path vertex) | w: int bits = light triangle the pending shadow ray must skip
+    float4* ray_o;      // extend-ray origin xyz (= previous path vertex) | w: int bits = light triangle the slot's shadow ray skips
     float4* ray_d;      // extend-ray direction xyz                        | w: uint bits, bit 0 = an extend ray is pending this iteration
     float4* hit;        // written by trace: int bits tri (leaf order) | lobe class << 28 (-1 = miss), u, v, t
-    float4* sh_d;       // pending shadow ray: direction xyz, t2 (origin = ray_o.xyz)
+    float4* sq_o;       // shadow-ray records, indexed like shadow_queue: origin xyz | w: int bits = the sampled light triangle to skip
+    float4* sq_d;       //                                                direction xyz | w: t2
     float4* nee;        // radiance the pending shadow ray carries if unoccluded (xyz) | w: uint, set non-zero by trace if the ray is
                         // blocked; otherwise xyz is added to L by the NEXT shade call
     float4* L;          // radiance of the current path so far xyz | w: pdf of the BSDF sample that produced the extend ray

@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
                 const float cos_theta = fabsf(dot(bsdf.w, ls.wo));
                 const float weight = power_heuristic(ls.pdf * rcp(nl), bpdf);
                 const f3 nee = weight * xyz(s_beta[src]) * ls.rad * fx * (cos_theta * rcp(ls.pdf) * nl);   // Render.cpp:127-129
-                s_hit[src] = mk4(ls.wo, ls.t2); s_nee[src] = mk4(nee, 0.f); out_flags |= OUT_SHADOW;   // the shadow ray: sh_d cell, NEE payload
+                s_hit[src] = mk4(ls.wo, ls.t2); s_nee[src] = mk4(nee, 0.f); out_flags |= OUT_SHADOW;   // the shadow ray's direction | t2, NEE payload
                 sh_skip = ls.tri; emit_shadow = true;
             }
         }
@@ -399,7 +399,10 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     if (emit_shadow) {
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
-        st_s(&pool.shadow_queue[base + before + lane_rank(ms)], slot);
+        // the shadow ray goes to the queue as a complete record (origin | triangle to skip, direction | t2, slot): the trace kernel reads a
+        // queued ray in ONE coalesced round trip instead of chasing queue -> slot -> ray records through two
+        const uint32_t q = base + before + lane_rank(ms);
+        st_s(&pool.shadow_queue[q], slot); st_s(&pool.sq_o[q], s_ro[src]); st_s(&pool.sq_d[q], s_hit[src]);
     }
     {   // the barrier above also published every slot's output cells: store the OWN slot's records, coalesced
         const uint32_t own = base + tid;
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         const uint32_t fl = __float_as_uint(rdo.w);
         st_s(&pool.beta[own], s_beta[tid]); st_s(&pool.L[own], s_L[tid]); st_s(&pool.ray_d[own], rdo);
         if (fl & OUT_RAY_O) st_s(&pool.ray_o[own], s_ro[tid]);
-        if (fl & OUT_SHADOW) { st_s(&pool.sh_d[own], s_hit[tid]); st_s(&pool.nee[own], s_nee[tid]); }
+        if (fl & OUT_SHADOW) st_s(&pool.nee[own], s_nee[tid]);
         if (fl & OUT_IDS) st_s(&pool.ids[own], s_ids[tid]);
     }
     // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
@@ -466,7 +469,8 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     lds_i32* stk = (lds_i32*)s_stack + threadIdx.x;
     lds_f4* top = (lds_f4*)s_top;
     const uint32_t ovf_stride = gridDim.x * WF_TRACE_BLOCK;
-    glb_i32* ovf = (glb_i32*)stack_overflow + (blockIdx.x * WF_TRACE_BLOCK + threadIdx.x);
+    // (the overflow area's per-lane base is recomputed where it is needed -- rarely -- instead of living in two registers)
+#define OVF(LEVEL) (((glb_i32*)stack_overflow)[(uint32_t)(LEVEL) * ovf_stride + (blockIdx.x * WF_TRACE_BLOCK + threadIdx.x)])   // 32-bit index math
     glb_cf4* gnodes = (glb_cf4*)sc.nodes4;
     const int n_top = sc.n_nodes4 < MCPT_TOP_NODES ? sc.n_nodes4 : MCPT_TOP_NODES;
     for (int i = threadIdx.x; i < 4 * n_top; i += WF_TRACE_BLOCK) s_top[(i & 3) * MCPT_TOP_NODES + (i >> 2)] = sc.nodes4[i];
@@ -500,9 +504,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     take_chunk(c_next++);
 
     bool have = false, any = false, blocked = false;
-    uint32_t slot = 0; int skip = -1;
+    uint32_t slot = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
-    float idx = 0, idy = 0, idz = 0, oodx = 0, oody = 0, oodz = 0, tmax = 0;
+    float idx = 0, idy = 0, idz = 0, tmax = 0;
     int node = MCPT_NODE_SENTINEL, sp = 1;
     int htri = -1; float hu = 0, hv = 0;
     uint32_t n_box = 0, n_tri = 0, n_spill = 0;     // n_spill: stack entries that went to the global overflow area (COUNT builds)
@@ -562,20 +566,19 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                         const float4 rd = ld_s(&pool.ray_d[my_w]);
                         valid = (__float_as_uint(rd.w) & 1u) != 0u;
                         const float4 ro = ld_s(&pool.ray_o[my_w]);
-                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; skip = -1;
+                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; htri = -1;
                     } else {                                             // shadow ray of a queued slot
                         slot = ld_s(&pool.shadow_queue[my_q + my_w]);
-                        const float4 ro = ld_s(&pool.ray_o[slot]), sd = ld_s(&pool.sh_d[slot]);
-                        o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; skip = __float_as_int(ro.w); valid = true;
+                        const float4 ro = ld_s(&pool.sq_o[my_q + my_w]), sd = ld_s(&pool.sq_d[my_q + my_w]);
+                        o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; htri = __float_as_int(ro.w); valid = true;   // htri: the light triangle to skip
                     }
                     if (valid) {
                         const float tiny = 1e-30f;
                         idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
                         idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
                         idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
-                        oodx = o.x * idx; oody = o.y * idy; oodz = o.z * idz;
                         stk[0] = MCPT_NODE_SENTINEL; sp = 1; node = 0;
-                        htri = -1; hu = 0.f; hv = 0.f; blocked = false;
+                        hu = 0.f; hv = 0.f; blocked = false;
                         have = true;
                     }
                 }
@@ -593,24 +596,43 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
             if (at_leaf) {
                 const uint32_t leaf = (uint32_t)~node;
                 const uint32_t first = leaf >> 3, cnt = leaf & 7u;
+                // The stack pop is requested BEFORE the triangle records, and a leaf's triangles are handled in pairs (a leaf of the SAH
+                // builder holds at most two).  The leaf block is 27 % of the waves' time at ~3 800 cycles per execution (tools/sched_stats.py).
+                const int sp1 = sp - 1;
+                int popped;
+                if (sp1 < WF_LDS_STACK) popped = stk[sp1 * WF_TRACE_BLOCK]; else popped = OVF(sp1 - WF_LDS_STACK);
                 bool done = false;
-                for (uint32_t i = 0; i < cnt && !done; i++) {
-                    const int ti = (int)(first + i);
-                    if (ti == skip) continue;
-                    const float4* T = sc.tri_isect + 3 * (size_t)ti;
-                    const float4 v0 = T[0], e1 = T[1], e2 = T[2];
-#ifndef WF_SCHED_STATS
-                    if (COUNT) n_tri++;
+#pragma unroll 1
+                for (uint32_t i = 0; i < cnt && !done; i += 2) {
+                    const int ta = (int)(first + i), tb = ta + 1;
+                    const bool use_a = !(any && ta == htri), use_b = i + 1 < cnt && !(any && tb == htri);   // any-hit rays keep their `skip` triangle in htri
+                    // (Fetching both records unconditionally -- no merge with a zero-initialised value, so the compiler requests b before it
+                    // waits for a -- costs 12 more registers (72 -> 84) and is a net loss: the trace kernel alone gains nothing (535 vs 536 ms)
+                    // and beside it one shade wave fewer fits on each SIMD (501 vs 484 ms per step).  -DWF_LEAF_UNCOND builds that form.)
+                    const float4* T = sc.tri_isect + 3 * (size_t)ta;
+#ifdef WF_LEAF_UNCOND
+                    const float4 v0a = T[0], e1a = T[1], e2a = T[2], v0b = T[3], e1b = T[4], e2b = T[5];   // tri_isect has one spare record at its end
+#else
+                    float4 v0a = make_float4(0, 0, 0, 0), e1a = v0a, e2a = v0a, v0b = v0a, e1b = v0a, e2b = v0a;
+                    if (use_a) { v0a = T[0]; e1a = T[1]; e2a = T[2]; }
+                    if (use_b) { v0b = T[3]; e1b = T[4]; e2b = T[5]; }
 #endif
-                    const TriTest r = tri_test(v0, e1, e2, o, d);
-                    if (any) {                                           // Triangle::isIntersect
-                        if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; }
-                    } else {                                             // Triangle::hit
-                        if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ti | __float_as_int(v0.w); hu = r.u; hv = r.v; }   // v0.w = lobe class << 28
+#ifndef WF_SCHED_STATS
+                    if (COUNT) n_tri += (use_a ? 1u : 0u) + (use_b ? 1u : 0u);
+#endif
+                    if (use_a) {
+                        const TriTest r = tri_test(v0a, e1a, e2a, o, d);
+                        if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }                     // Triangle::isIntersect
+                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ta | __float_as_int(v0a.w); hu = r.u; hv = r.v; }   // Triangle::hit; v0.w = lobe class << 28
+                    }
+                    if (use_b && !done) {
+                        const TriTest r = tri_test(v0b, e1b, e2b, o, d);
+                        if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }
+                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = tb | __float_as_int(v0b.w); hu = r.u; hv = r.v; }
                     }
                 }
                 if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
-                else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
+                else { sp = sp1; node = popped; }
             }
             WF_TICK(t_leaf)
             continue;
@@ -632,7 +654,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                 const uint32_t meta = __float_as_uint(A.w);
                 const float ax = __uint_as_float((meta & 0xffu) << 23) * idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy,
                             az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
-                const float bx = fmaf(A.x, idx, -oodx), by = fmaf(A.y, idy, -oody), bz = fmaf(A.z, idz, -oodz);
+                const float bx = (A.x - o.x) * idx, by = (A.y - o.y) * idy, bz = (A.z - o.z) * idz;   // (node origin - ray origin) / d: no o/d registers kept
                 // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise (and vice versa for the
                 // exit planes): selecting the packed words once per node replaces a min and a max per axis per child
                 const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
@@ -672,11 +694,11 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     node = hit0 ? cd0 : below;
                     sp -= hit0 ? 0 : 1;
                 } else {                                                   // rare: near the LDS limit -> entries may go to the overflow area
-                    if (h3) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd3; else { ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd3; if (COUNT) n_spill++; } sp++; }
-                    if (h2) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd2; else { ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd2; if (COUNT) n_spill++; } sp++; }
-                    if (h1) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd1; else { ovf[(sp - WF_LDS_STACK) * ovf_stride] = cd1; if (COUNT) n_spill++; } sp++; }
+                    if (h3) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd3; else { OVF(sp - WF_LDS_STACK) = cd3; if (COUNT) n_spill++; } sp++; }
+                    if (h2) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd2; else { OVF(sp - WF_LDS_STACK) = cd2; if (COUNT) n_spill++; } sp++; }
+                    if (h1) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd1; else { OVF(sp - WF_LDS_STACK) = cd1; if (COUNT) n_spill++; } sp++; }
                     if (key0 < inf) node = cd0;
-                    else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = ovf[(sp - WF_LDS_STACK) * ovf_stride]; }
+                    else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = OVF(sp - WF_LDS_STACK); }
                 }
             }
             if (greedy) {                                                  // stay while inner nodes are still what most lanes wait for
@@ -704,6 +726,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     }
 }
 
+#undef OVF
 // ====================================================================================================== launchers
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
                            float4* accum, DevCounters* cnt, hipStream_t stream) {
