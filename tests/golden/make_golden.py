@@ -13,6 +13,10 @@ Files:
   ref_paths.npz        path-level vectors: (pixel, xi sequence) -> radiance of Render::ray_tracing, both integrators,
                        plus BVH::hit / has_hit on random rays, on the S-cornell-small scene
   ref_images.npz       per-pixel mean / variance images of the reference renderer (64x64) for statistical parity
+  ref_scenes2.npz      (round 2) the same path-level pins on two more scenes -- S-veach small (480 light triangles, Blinn-Phong
+                       exponents 10..5000) and S-bath small (image textures, mirror Ns = 10000, glossy chrome): injected-xi full
+                       paths, BVH::hit / has_hit ray records, light samples, and default-mode mean / variance images
+                       (`python tests/golden/make_golden.py scenes2` writes only this file)
 """
 import os
 import sys
@@ -177,8 +181,62 @@ def image_stats(scene, lib_depth, max_bounces, frames, batches):
     return means.mean(0).astype(np.float32), (means.var(0, ddof=1) / batches).astype(np.float32)
 
 
+SCENES2 = {   # tag: (generator, kwargs, (w, h), box the probe rays / shading points are drawn from)
+    "vm_": ("veach-mis", {"light_lon": 12, "light_lat": 6, "plate_cells": 4}, (64, 36), ((-6.0, 0.0, -5.0), (6.0, 6.0, 8.0))),
+    "bt_": ("bathroom2", {"detail": 12, "tex_size": 32}, (64, 36), ((0.1, 0.1, 0.1), (3.9, 2.5, 4.9))),
+}
+
+
+def scene2_vectors(ref, scene, tag, box):
+    """Path-level pins on one more scene (same record layouts as scene_vectors)."""
+    rng = np.random.RandomState(4242)
+    out = {}
+    w, h = scene.camera.width, scene.camera.height
+    lo, hi = np.array(box[0]), np.array(box[1])
+    n = 2000
+    o = rng.uniform(lo, hi, (n, 3)); d = unit(rng.normal(size=(n, 3)))
+    rec = np.zeros((n, 12)); hit = np.zeros(n, np.int32); anyh = np.zeros(n, np.int32); t2 = rng.uniform(0.05, 0.6, n) * np.linalg.norm(hi - lo)
+    for i in range(n):
+        hit[i], rec[i] = ref.bvh_hit(o[i], d[i])
+        anyh[i] = ref.bvh_has_hit(o[i], d[i], 1e-4, t2[i])
+    out.update({tag + "ray_o": o, tag + "ray_d": d, tag + "ray_hit": hit, tag + "ray_rec": rec, tag + "ray_t2": t2, tag + "ray_any": anyh})
+    n = 400
+    p = rng.uniform(lo, hi, (n, 3)); xi = np.stack([rand_xi(rng, n) for _ in range(3)], 1)
+    ls = np.zeros((n, 14))
+    for i in range(n):
+        ls[i], _ = ref.sample_light(p[i], xi[i])
+    out.update({tag + "ls_p": p, tag + "ls_xi": xi, tag + "ls_out": ls})
+    n, m = 1200, 320
+    xy = np.stack([rng.randint(0, w, n), rng.randint(0, h, n)], 1).astype(np.int32)
+    xi = np.stack([rand_xi(rng, m) for _ in range(n)], 0)
+    L = np.zeros((n, 3), np.float32); used = np.zeros(n, np.int32)
+    for i in range(n):
+        L[i], used[i] = ref.trace_pixel(int(xy[i, 0]), int(xy[i, 1]), xi[i])
+    assert ref.underflow() == 0 and used.max() < m, "xi budget too small"
+    out.update({tag + "path_xy": xy, tag + "path_xi": xi[:, :used.max() + 2].copy(), tag + "path_L": L, tag + "path_used": used})
+    st = ref.bvh_stats()
+    out[tag + "bvh"] = np.array([st["nodes"], st["leaves"], st["depth"], st["max_leaf"], ref.num_tris(), ref.num_lights()], np.int64)
+    return out
+
+
+def scenes2():
+    out = {}
+    for tag, (name, kw, res, box) in SCENES2.items():
+        scene = pkg.scenes.SCENES[name](res[0], res[1], **kw)
+        tmp = tempfile.mkdtemp(prefix="mcpt_golden_")
+        ref = orc.Reference()
+        ref.load(scene.write(tmp))
+        out.update(scene2_vectors(ref, scene, tag, box))
+        m, v = image_stats(scene, False, 0, 64, 16)
+        out.update({tag + "unbounded_mean": m, tag + "unbounded_var": v})
+        print(tag, "done: tris", ref.num_tris(), "lights", ref.num_lights(), "image mean", m.mean((0, 1)))
+    np.savez_compressed(os.path.join(HERE, "ref_scenes2.npz"), **out)
+
+
 def main():
     os.environ["OMP_NUM_THREADS"] = "1"     # the reference's global mt19937 is racy across threads; single-threaded = reproducible
+    if len(sys.argv) > 1 and sys.argv[1] == "scenes2":
+        scenes2(); return
     scene = pkg.scenes.cornell_box_small(64, 64)
     tmp = tempfile.mkdtemp(prefix="mcpt_golden_")
     ref = orc.Reference()
@@ -200,6 +258,7 @@ def main():
     m, v = image_stats(ob, False, 0, 64, 16); imgs.update(ob_unbounded_mean=m, ob_unbounded_var=v)
     np.savez_compressed(os.path.join(HERE, "ref_images.npz"), **imgs)
     print("images written")
+    scenes2()
 
 
 if __name__ == "__main__":

@@ -66,8 +66,8 @@ def test_same_seed_image_parity_stable_mode(pkg, orc, max_depth, pipeline):
     gm, cm = g[..., :3] / spp, cpu[..., :3] / spp
     frac = _frac_beyond(gm, cm)
     print("pixels beyond tolerance: %.3f%%  image mean gpu %s cpu %s" % (100 * frac, gm.mean((0, 1)), cm.mean((0, 1))))
-    assert frac <= 0.01
-    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=2e-3)
+    assert frac <= 0.001                                  # >= 99.9 % of pixels (measured 99.976 %)
+    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=1e-4)
     assert c.paths == oc["paths"] == 64 * 64 * spp
     assert c.rays_primary == oc["rays_primary"]
     assert abs(int(c.rays_continuation) - oc["rays_continuation"]) <= 0.002 * oc["rays_continuation"]
@@ -89,9 +89,9 @@ def test_wavefront_and_megakernel_agree(pkg):
     assert np.allclose(out[0][..., :3].mean((0, 1)), out[1][..., :3].mean((0, 1)), rtol=1e-3)
 
 
-@pytest.mark.parametrize("name,kw,res", [("veach-mis", {"light_lon": 12, "light_lat": 6, "plate_cells": 4}, (64, 36)),
-                                         ("bathroom2", {"detail": 12, "tex_size": 32}, (64, 36))])
-def test_same_seed_other_scenes(pkg, orc, name, kw, res):
+@pytest.mark.parametrize("name,kw,res,max_frac", [("veach-mis", {"light_lon": 12, "light_lat": 6, "plate_cells": 4}, (64, 36), 0.001),
+                                                  ("bathroom2", {"detail": 12, "tex_size": 32}, (64, 36), 0.01)])
+def test_same_seed_other_scenes(pkg, orc, name, kw, res, max_frac):
     """S-veach (1440 light triangles, four Blinn-Phong exponents) and S-bath (image textures, mirror Ns=10000, glossy chrome)."""
     scene = pkg.scenes.SCENES[name](res[0], res[1], **kw)
     flags = pkg.FLAG_CORRECT_SHADOW_T2
@@ -100,8 +100,10 @@ def test_same_seed_other_scenes(pkg, orc, name, kw, res):
     gm, cm = g[..., :3] / 16, cpu[..., :3] / 16
     frac = _frac_beyond(gm, cm)
     print(name, "pixels beyond tolerance: %.3f%%" % (100 * frac), gm.mean((0, 1)), cm.mean((0, 1)))
-    assert frac <= 0.02
-    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=5e-3)
+    # measured: S-veach 0.000 %, S-bath 0.74 % (mirror + Ns = 2000 chrome: a 1e-7 difference in a reflected direction moves the next hit
+    # across a texel or triangle edge -- path divergence, not bias: the image means agree to 3e-6)
+    assert frac <= max_frac
+    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=1e-4)
 
 
 def test_recursive_nee_integrator(pkg, orc):
@@ -113,6 +115,61 @@ def test_recursive_nee_integrator(pkg, orc):
     gm, cm = g[..., :3] / 16, cpu[..., :3] / 16
     assert _frac_beyond(gm, cm) <= 0.01
     assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=2e-3)
+
+
+def _transformed(pkg, scene, scale=1.0, offset=(0.0, 0.0, 0.0)):
+    """The same scene scaled about the origin and translated (vertices and camera; every number re-quantised to its file form)."""
+    S = pkg.scenes
+    off = np.asarray(offset, float)
+    v = np.vectorize(S._q)(scene.vertex * scale + off)
+    c = scene.camera
+    cam = S._qcam(tuple(np.asarray(c.eye) * scale + off), tuple(np.asarray(c.lookat) * scale + off), c.up, c.fovy, c.width, c.height)
+    return S.SceneData(scene.name + "-moved", v, scene.normal, scene.texcoord, scene.face, scene.materials, cam, dict(scene.meta))
+
+
+@pytest.mark.parametrize("scale,offset,max_frac,mean_rtol", [(1.0, (100.0, -3.0, 0.25), 0.06, 5e-4), (100.0, (0.0, 0.0, 0.0), 0.04, 5e-4),
+                                                             (0.01, (0.0, 0.0, 0.0), 0.002, 1e-4), (1.0, (1000.0, -3.0, 0.25), None, 5e-3),
+                                                             (1.0, (5e4, -3.0, 0.25), None, 0.10)])
+def test_fp32_traversal_envelope_vs_fp64_oracle(pkg, orc, scale, offset, max_frac, mean_rtol):
+    """The device intersects in fp32 with the reference's ABSOLUTE ray epsilon t1 = 1e-4 (Render.h:30); the reference (and the oracle)
+    intersect in fp64.  Same seed, S-cornell-small moved away from the origin / rescaled.  Measured on MI355X (pixels beyond
+    1e-4 | relative image-mean difference): at the origin 0.02 % | 1e-6; offset 100: 2.9 % | 7e-5; box scaled x100: 1.7 % | 3e-5;
+    scaled x0.01 (t1 = 1 % of the box; both sides lose the same contact shadows): 0.00 %; offset 1000 (fp32 spacing 6e-5 ~ t1):
+    29 % | 1.3e-3; offset 5e4 (fp32 spacing 4e-3 >> t1: new rays start up to 2 mm off the surface and re-hit it): 94 % | 5 % darker.
+    => the fp32 path carries the reference's results while |coordinate| * 2^-23 << 1e-4, i.e. scenes within ~10^2..10^3 units of the
+    origin (all three cg24 scenes are); beyond that it degrades gracefully (finite film, percent-level bias), which DESIGN.md states."""
+    scene = _transformed(pkg, pkg.scenes.cornell_box_small(64, 64), scale, offset)
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    r = pkg.Renderer(scene, max_depth=6, flags=flags); r.render(16, seed=3); g = r.read_accum(); r.close()
+    cpu, _, _ = orc.Oracle(scene, max_depth=6, flags=flags).render(16, seed=3)
+    gm, cm = g[..., :3] / 16, cpu[..., :3] / 16
+    frac = _frac_beyond(gm, cm)
+    print("scale %g offset %s: pixels beyond tolerance %.2f%%  mean gpu %s cpu %s" % (scale, offset, 100 * frac, gm.mean((0, 1)), cm.mean((0, 1))))
+    assert np.isfinite(g).all() and np.all(g[..., 3] == 16)
+    if max_frac is not None:
+        assert frac <= max_frac
+    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=mean_rtol)
+
+
+def test_nan_samples_are_scrubbed_like_set_pixel(pkg, orc):
+    """Scene::set_Pixel zeroes NaN components of a sample before adding it and still counts the sample (Scene.cpp:16-20).  Zero vertex
+    normals on the floor make normalize(0) = NaN the shading normal of every floor hit: the film must stay finite, every pixel
+    must have received all its samples, and in the stable mode the film equals the oracle's sample for sample."""
+    S = pkg.scenes
+    nb = S.open_box(32, 32)
+    nrm = nb.normal.copy(); nrm[np.unique(nb.face[:2, :, 1])] = 0.0          # the floor's two triangles
+    scene = S.SceneData("nan-box", nb.vertex, nrm, nb.texcoord, nb.face, nb.materials, nb.camera, {})
+    for fl in (pkg.FLAG_CORRECT_SHADOW_T2, 0):
+        r = pkg.Renderer(scene, max_depth=4, flags=fl); r.render(16, seed=1); g = r.read_accum(); r.close()
+        cpu, _, _ = orc.Oracle(scene, max_depth=4, flags=fl).render(16, seed=1)
+        assert np.isfinite(g).all() and np.all(g[..., 3] == 16) and np.isfinite(cpu).all()
+        clean = S.open_box(32, 32)
+        r = pkg.Renderer(clean, max_depth=4, flags=fl); r.render(16, seed=1); gc = r.read_accum(); r.close()
+        assert g[..., :3].sum() < 0.9 * gc[..., :3].sum()                     # the NaN samples really were dropped to zero
+        if fl:
+            assert _frac_beyond(g[..., :3] / 16, cpu[..., :3] / 16) <= 0.002
+        else:
+            assert np.allclose((g[..., :3] / 16).mean((0, 1)), (cpu[..., :3] / 16).mean((0, 1)), rtol=0.05)
 
 
 # ------------------------------------------------------------------------------------------------ statistics vs the real reference
@@ -133,6 +190,55 @@ def test_gpu_matches_reference_statistics(pkg, images, name, max_depth, scene_fn
     frac = float((z > 4).mean())
     print(name, "gpu", mean.mean((0, 1)), "reference", rm.mean((0, 1)), "pixels > 4 sigma %.3f%%" % (100 * frac))
     assert frac <= 0.006
+
+
+SCENES2 = {"vm_": ("veach-mis", {"light_lon": 12, "light_lat": 6, "plate_cells": 4}, (64, 36)),
+           "bt_": ("bathroom2", {"detail": 12, "tex_size": 32}, (64, 36))}
+
+
+@pytest.fixture(scope="module")
+def g2():
+    return _npz("ref_scenes2.npz")
+
+
+@pytest.mark.parametrize("tag", sorted(SCENES2))
+def test_gpu_matches_reference_statistics_more_scenes(pkg, g2, tag):
+    """Default (reference-faithful, A-9) mode against the REAL reference's per-pixel mean / variance on S-veach small (480 light
+    triangles, Blinn-Phong exponents up to 5000) and S-bath small (image textures, mirror, chrome) -- tests/golden/ref_scenes2.npz."""
+    name, kw, res = SCENES2[tag]
+    scene = pkg.scenes.SCENES[name](res[0], res[1], **kw)
+    r = pkg.Renderer(scene)
+    means = []
+    for b in range(16):
+        r.clear(); r.render(256, seed=321, first_sample=b * 256); a = r.read_accum(); means.append(a[..., :3] / a[..., 3:])
+    r.close()
+    m = np.stack(means); mean, var = m.mean(0), m.var(0, ddof=1) / 16
+    rm, rv = g2[tag + "unbounded_mean"], g2[tag + "unbounded_var"]
+    npix = rm.shape[0] * rm.shape[1]
+    se = np.sqrt(var.sum((0, 1)) + rv.sum((0, 1))) / npix             # standard error of the difference of the two image means
+    dm = np.abs(mean.mean((0, 1)) - rm.mean((0, 1)))
+    z = np.abs(mean - rm) / np.sqrt(var + rv + 1e-12)
+    frac = float((z > 4).mean())
+    print(tag, "gpu", mean.mean((0, 1)), "reference", rm.mean((0, 1)), "se", se, "pixels > 4 sigma %.3f%%" % (100 * frac))
+    assert np.all(dm <= 4 * se) and np.all(dm <= 0.03 * rm.mean((0, 1)))
+    assert frac <= 0.006
+
+
+@pytest.mark.parametrize("tag", sorted(SCENES2))
+@pytest.mark.parametrize("tree", ["host-sah", "device-lbvh"])
+def test_probe_trace4_vs_reference_more_scenes(pkg, g2, tag, tree):
+    """BVH::hit / has_hit of the REAL reference on 2 000 rays per scene through the production trace kernel."""
+    name, kw, res = SCENES2[tag]
+    r = pkg.Renderer(pkg.scenes.SCENES[name](res[0], res[1], **kw), flags=pkg.FLAG_GPU_BVH_BUILD if tree == "device-lbvh" else 0)
+    t, tri, u, v = r.probe_trace4(g2[tag + "ray_o"], g2[tag + "ray_d"])
+    anyh = r.probe_trace4(g2[tag + "ray_o"], g2[tag + "ray_d"], t2=g2[tag + "ray_t2"], any_hit=True)[1]
+    r.close()
+    ref_tri = g2[tag + "ray_rec"][:, 11].astype(np.int32); ref_hit = g2[tag + "ray_hit"] == 1
+    same = (tri == np.where(ref_hit, ref_tri, -1))
+    assert same.mean() >= 0.998, same.mean()
+    ok = same & ref_hit
+    assert np.allclose(t[ok], g2[tag + "ray_rec"][ok, 0], rtol=2e-5, atol=2e-6)
+    assert (anyh == g2[tag + "ray_any"]).mean() >= 0.998
 
 
 def test_self_occlusion_rate_matches_oracle(pkg, orc):
@@ -512,8 +618,8 @@ def test_c5_same_seed_vs_oracle_small_view(pkg, orc, c5_scene):
     print("C5 small view: pixels beyond tolerance %.3f%%  mean gpu %s cpu %s  box tests/ray %.1f tri tests/ray %.2f spills %d  oracle %.1f s" % (
         100 * frac, gm.mean((0, 1)), cm.mean((0, 1)), c.box_tests / c.rays, c.tri_tests / c.rays, c.stack_spills, secs))
     assert np.all(g[..., 3] == spp)
-    assert frac <= 0.02
-    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=1e-2)
+    assert frac <= 0.005                                  # measured 0.22 %
+    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=1e-4)
     assert c.rays_primary == oc["rays_primary"] == 64 * 36 * spp
     assert abs(int(c.rays_continuation) - oc["rays_continuation"]) <= 0.01 * oc["rays_continuation"]
 
