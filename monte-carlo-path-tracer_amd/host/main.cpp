@@ -17,7 +17,7 @@
 
 static void usage() {
     std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
-                 "                          [--deterministic] [--ref-index-order] [--gpu-bvh] [--check]\n"
+                 "                          [--deterministic] [--ref-index-order] [--gpu-bvh] [--check] [--dump-model file]\n"
                  "       mcpt_cli --decode-image texture.(png|jpg|ppm) out.ppm\n";
 }
 
@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
         std::fprintf(f, "P6\n%d %d\n255\n", w, h); std::fwrite(rgb.data(), 1, rgb.size(), f); std::fclose(f);
         return 0;
     }
-    std::string filename = argv[1], out;
+    std::string filename = argv[1], out, dump_model;
     uint32_t spp = 64, batch = 0, depth = 0, gpus = 1; uint64_t seed = 20251004; uint32_t flags = 0, integrator = 0; bool ref_order = false, check_only = false;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i]; auto next = [&]() { return i + 1 < argc ? argv[++i] : (char*)"0"; };
@@ -43,11 +43,31 @@ int main(int argc, char** argv) {
         else if (a == "--deterministic") flags |= MCPT_FLAG_DETERMINISTIC; else if (a == "--ref-index-order") ref_order = true;
         else if (a == "--gpu-bvh") flags |= MCPT_FLAG_GPU_BVH_BUILD;
         else if (a == "--check") check_only = true;
+        else if (a == "--dump-model") dump_model = next();
         else { usage(); return 2; }
     }
     Model model(filename, ref_order);
     if (!model.ok) { std::cerr << "Error: scene did not load" << std::endl; return 1; }
     std::cout << model.face.size() << " " << model.normal.size() << " " << model.vertex.size() << std::endl;   // main.cpp:14
+    if (!dump_model.empty()) {   // host-only: everything Model(filename) parsed, as text (tests compare it with the reference's own parse)
+        FILE* f = std::fopen(dump_model.c_str(), "w");
+        if (!f) { std::cerr << "Error: cannot write " << dump_model << std::endl; return 1; }
+        std::fprintf(f, "counts %zu %zu %zu %zu %zu %d %d\n", model.vertex.size(), model.normal.size(), model.texture.size(), model.face.size(), model.materials.size(),
+                     model.camerainfo.width, model.camerainfo.height);
+        for (auto& v : model.vertex) std::fprintf(f, "v %.17g %.17g %.17g\n", v.x, v.y, v.z);
+        for (auto& v : model.normal) std::fprintf(f, "vn %.17g %.17g %.17g\n", v.x, v.y, v.z);
+        for (auto& v : model.texture) std::fprintf(f, "vt %.17g %.17g\n", v.x, v.y);
+        for (auto& fc : model.face) { std::fprintf(f, "f"); for (int c = 0; c < 3; c++) for (int k = 0; k < 4; k++) std::fprintf(f, " %d", fc[c][k]); std::fprintf(f, "\n"); }
+        for (auto& m : model.materials) {
+            std::fprintf(f, "m %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %zu %d %d\n", m.Ks.x, m.Ks.y, m.Ks.z, m.Tr.x, m.Tr.y, m.Tr.z, m.Ns, m.Ni,
+                         m.radiance.x, m.radiance.y, m.radiance.z, m.Map_Kd->image_color.size(), m.Map_Kd->image_w, m.Map_Kd->image_h);
+            std::fprintf(f, "t"); for (auto& c : m.Map_Kd->image_color) std::fprintf(f, " %.9g %.9g %.9g", c.x, c.y, c.z); std::fprintf(f, "\n");
+        }
+        const CameraInfo& c = model.camerainfo;
+        std::fprintf(f, "c %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", c.eye.x, c.eye.y, c.eye.z, c.lookat.x, c.lookat.y, c.lookat.z, c.up.x, c.up.y, c.up.z, c.fovy);
+        std::fclose(f);
+        if (!check_only) return 0;
+    }
     if (check_only) {   // host-only: what the loader produced + what the library's flatten / BVH build makes of it (no GPU needed)
         std::vector<mcpt_material> mats; std::vector<mcpt_texture> texs; mcpt_scene_desc d; mcpt_scene_info info;
         model_to_desc(model, mats, texs, d);

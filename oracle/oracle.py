@@ -249,6 +249,26 @@ class Reference:
         self.L = L
         self.depth_variant = depth_variant
 
+    def parse_model(self, obj_path):
+        """Model(filename) of the reference alone (model.cpp:44-281), as plain arrays."""
+        L = self.L
+        L.ref_model_load.argtypes = [C.c_char_p]; L.ref_model_counts.argtypes = [vp]; L.ref_model_arrays.argtypes = [vp, vp, vp, vp]
+        L.ref_model_material.argtypes = [C.c_int, vp]; L.ref_model_texels.argtypes = [C.c_int, vp]; L.ref_model_camera.argtypes = [vp]
+        L.ref_model_load(obj_path.encode())
+        cnt = np.zeros(7, np.int32); L.ref_model_counts(_p(cnt))
+        nv, nn, nt, nf, nm, w, h = [int(x) for x in cnt]
+        v = np.zeros((nv, 3)); vn = np.zeros((nn, 3)); vt = np.zeros((nt, 2)); f = np.zeros((nf, 3, 4), np.int32)
+        L.ref_model_arrays(_p(v), _p(vn), _p(vt), _p(f))
+        mats = np.zeros((nm, 14)); texels = []
+        for i in range(nm):
+            L.ref_model_material(i, _p(mats[i]))
+            t = np.zeros((int(mats[i, 11]), 3), np.float32)
+            if len(t):
+                L.ref_model_texels(i, _p(t))
+            texels.append(t)
+        cam = np.zeros(10); L.ref_model_camera(_p(cam))
+        return dict(vertex=v, normal=vn, texcoord=vt, face=f, materials=mats, texels=texels, camera=cam, width=w, height=h)
+
     def load(self, obj_path):
         # the reference prints "[Model] path" to stdout (model.cpp:46); harmless
         if self.L.ref_load(obj_path.encode()) != 0:

@@ -62,6 +62,41 @@ void ref_set_max_bounces(int n) { mcpt_refshim::g_max_bounces = n <= 0 ? INT_MAX
 float ref_rand1f() { return rand1f(); }
 
 // ---------------------------------------------------------------- scene (main.cpp:13-17)
+// ---------------------------------------------------------------- the loader alone (model.cpp:44-281): what Model(filename) parsed
+// A Model that is never handed to Render, so files that exercise the parser's quirks (a material without Kd leaves Map_Kd null,
+// model.h:38) can be inspected without running into the renderer's own undefined behaviour.
+std::unique_ptr<Model> g_parsed;
+int ref_model_load(const char* obj_path) { g_parsed.reset(new Model(obj_path)); return 0; }
+void ref_model_counts(int* out7) {
+    out7[0] = int(g_parsed->vertex.size()); out7[1] = int(g_parsed->normal.size()); out7[2] = int(g_parsed->texture.size());
+    out7[3] = int(g_parsed->face.size()); out7[4] = int(g_parsed->materials.size());
+    out7[5] = g_parsed->camerainfo.width; out7[6] = g_parsed->camerainfo.height;
+}
+void ref_model_arrays(double* v3, double* vn3, double* vt2, int* f12) {
+    for (size_t i = 0; i < g_parsed->vertex.size(); i++) put3(v3 + 3 * i, g_parsed->vertex[i]);
+    for (size_t i = 0; i < g_parsed->normal.size(); i++) put3(vn3 + 3 * i, g_parsed->normal[i]);
+    for (size_t i = 0; i < g_parsed->texture.size(); i++) { vt2[2 * i] = g_parsed->texture[i].x; vt2[2 * i + 1] = g_parsed->texture[i].y; }
+    for (size_t i = 0; i < g_parsed->face.size(); i++)
+        for (int c = 0; c < 3; c++) for (int k = 0; k < 4; k++) f12[12 * i + 4 * c + k] = g_parsed->face[i][c][k];
+}
+// per material: Ks[3], Tr[3], Ns, Ni, radiance[3], number of texels of Map_Kd (0 = Map_Kd is null), image_w, image_h
+void ref_model_material(int i, double* out14) {
+    const Material& m = g_parsed->materials[size_t(i)];
+    put3(out14, m.Ks); put3(out14 + 3, m.Tr); out14[6] = m.Ns; out14[7] = m.Ni; put3(out14 + 8, m.radiance);
+    out14[11] = m.Map_Kd ? double(m.Map_Kd->image_color.size()) : 0.0;
+    out14[12] = (m.Map_Kd && m.Map_Kd->image_color.size() > 1) ? double(m.Map_Kd->image_w) : 1.0;
+    out14[13] = (m.Map_Kd && m.Map_Kd->image_color.size() > 1) ? double(m.Map_Kd->image_h) : 1.0;
+}
+void ref_model_texels(int i, float* rgb) {
+    const Material& m = g_parsed->materials[size_t(i)];
+    if (!m.Map_Kd) return;
+    for (size_t k = 0; k < m.Map_Kd->image_color.size(); k++) put3f(rgb + 3 * k, m.Map_Kd->image_color[k]);
+}
+void ref_model_camera(double* out10) {
+    const CameraInfo& c = g_parsed->camerainfo;
+    put3(out10, c.eye); put3(out10 + 3, c.lookat); put3(out10 + 6, c.up); out10[9] = c.fovy;
+}
+
 int ref_load(const char* obj_path) {
     g_model.reset(new Model(obj_path));
     if (g_model->face.empty()) return -1;

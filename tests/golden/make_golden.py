@@ -17,6 +17,8 @@ Files:
                        exponents 10..5000) and S-bath small (image textures, mirror Ns = 10000, glossy chrome): injected-xi full
                        paths, BVH::hit / has_hit ray records, light samples, and default-mode mean / variance images
                        (`python tests/golden/make_golden.py scenes2` writes only this file)
+  ref_loader.npz       (round 2) the reference's own Model(filename) parse of tests/golden/loader_quirks/quirk.obj (this project's
+                       quirk-exercising input) and of a scenes.py-written S-bath small (`... make_golden.py loader`)
 """
 import os
 import sys
@@ -233,10 +235,32 @@ def scenes2():
     np.savez_compressed(os.path.join(HERE, "ref_scenes2.npz"), **out)
 
 
+def loader():
+    """ref_loader.npz: what the reference's OWN Model(filename) (model.cpp:44-281) parses from (a) tests/golden/loader_quirks/quirk.obj
+    -- this project's test input exercising the parser's quirks: a 4-corner face, a/b/c with b != c, text after the numbers of a `v`
+    line, a line starting with a blank, `#` in the middle of an MTL line, a material without Kd, an unknown usemtl, a PNG map_Kd, a
+    <light> for a material that does not exist -- and (b) the OBJ/MTL/XML/PPM files scenes.py writes for S-bath small."""
+    out = {}
+    ref = orc.Reference()
+    cases = {"quirk_": os.path.join(HERE, "loader_quirks", "quirk.obj"),
+             "bath_": pkg.scenes.bathroom_stress(64, 36, detail=12, tex_size=32).write(tempfile.mkdtemp(prefix="mcpt_golden_"))}
+    for tag, path in cases.items():
+        m = ref.parse_model(path)
+        for k in ("vertex", "normal", "texcoord", "face", "materials", "camera"):
+            out[tag + k] = m[k]
+        out[tag + "size"] = np.array([m["width"], m["height"]], np.int32)
+        for i, t in enumerate(m["texels"]):
+            out[tag + "texels%d" % i] = t
+    np.savez_compressed(os.path.join(HERE, "ref_loader.npz"), **out)
+    print("loader golden written:", {k: v.shape for k, v in out.items() if k.startswith("quirk_")})
+
+
 def main():
     os.environ["OMP_NUM_THREADS"] = "1"     # the reference's global mt19937 is racy across threads; single-threaded = reproducible
     if len(sys.argv) > 1 and sys.argv[1] == "scenes2":
         scenes2(); return
+    if len(sys.argv) > 1 and sys.argv[1] == "loader":
+        loader(); return
     scene = pkg.scenes.cornell_box_small(64, 64)
     tmp = tempfile.mkdtemp(prefix="mcpt_golden_")
     ref = orc.Reference()
@@ -259,6 +283,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_images.npz"), **imgs)
     print("images written")
     scenes2()
+    loader()
 
 
 if __name__ == "__main__":

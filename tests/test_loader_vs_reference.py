@@ -1,0 +1,103 @@
+"""CPU tests (no GPU): the C++ host loader (host/Model.cpp through `mcpt_cli --dump-model`) against the REFERENCE'S OWN parser
+(src/model.cpp:44-281, compiled into oracle/_ref and driven through ref_model_* in oracle/ref/ref_driver.cpp).
+
+Golden = tests/golden/ref_loader.npz (the reference's parse, written by tests/golden/make_golden.py loader); inputs =
+tests/golden/loader_quirks/ (this project's own quirk-exercising OBJ / MTL / XML / PNG) and the files scenes.py writes.  With
+oracle/_ref present the comparison is repeated live.  `--ref-index-order` is the reference's reading of `f a/b/c` (second index =
+normal, third = texcoord, Render.cpp:19-26: SURVEY A-14); without it the loader follows Wavefront (v/vt/vn)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+G = os.path.join(HERE, "golden")
+CLI = os.path.join(ROOT, "monte-carlo-path-tracer_amd", "csrc", "mcpt_cli")
+QUIRK = os.path.join(G, "loader_quirks", "quirk.obj")
+
+
+def _dump(obj, tmp_path, ref_order=True):
+    out = str(tmp_path / "model.txt")
+    cmd = [CLI, obj, "--dump-model", out] + (["--ref-index-order"] if ref_order else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    m = {"vertex": [], "normal": [], "texcoord": [], "face": [], "materials": [], "texels": []}
+    for line in open(out):
+        k, *v = line.split()
+        if k == "counts": m["counts"] = [int(x) for x in v]
+        elif k == "v": m["vertex"].append([float(x) for x in v])
+        elif k == "vn": m["normal"].append([float(x) for x in v])
+        elif k == "vt": m["texcoord"].append([float(x) for x in v])
+        elif k == "f": m["face"].append([int(x) for x in v])
+        elif k == "m": m["materials"].append([float(x) for x in v])
+        elif k == "t": m["texels"].append(np.array([float(x) for x in v], np.float32).reshape(-1, 3))
+        elif k == "c": m["camera"] = np.array([float(x) for x in v])
+    for k in ("vertex", "normal", "texcoord", "materials"):
+        m[k] = np.array(m[k], float)
+    m["face"] = np.array(m["face"], np.int32).reshape(-1, 3, 4)
+    return m
+
+
+def _compare(mine, ref, tag=""):
+    """ref: dict with the reference's arrays (golden or live)."""
+    assert np.array_equal(mine["vertex"], ref["vertex"]) and np.array_equal(mine["normal"], ref["normal"]) and np.array_equal(mine["texcoord"], ref["texcoord"])
+    assert np.array_equal(mine["face"], ref["face"])                      # first three corners only, a/b/c -> [v, normal, texcoord], material per usemtl
+    assert np.array_equal(mine["camera"], ref["camera"]) and mine["counts"][5:7] == [int(ref["size"][0]), int(ref["size"][1])]
+    rm = ref["materials"]
+    assert mine["materials"].shape[0] == rm.shape[0]
+    for i in range(rm.shape[0]):
+        assert np.array_equal(mine["materials"][i, :11], rm[i, :11]), (tag, i)   # Ks, Tr, Ns, Ni, radiance: bit for bit (stod both sides)
+        n_ref = int(rm[i, 11])
+        if n_ref == 0:
+            # a material without Kd: the reference leaves Map_Kd null (model.h:38) and dereferences it at the first hit (BSDF.cpp:92);
+            # this loader defines it as a constant black texture
+            assert mine["texels"][i].shape == (1, 3) and not mine["texels"][i].any()
+        else:
+            assert int(mine["materials"][i, 11]) == n_ref
+            if n_ref > 1:
+                assert (int(mine["materials"][i, 12]), int(mine["materials"][i, 13])) == (int(rm[i, 12]), int(rm[i, 13]))
+            # texels: stbi_loadf = pow(c / 255, 2.2) in float -- libm powf both sides, a few ulp apart at most
+            assert np.allclose(mine["texels"][i], ref["texels"][i], rtol=2e-6, atol=1e-7), (tag, i)
+
+
+def _golden(tag):
+    with np.load(os.path.join(G, "ref_loader.npz")) as z:
+        d = {k[len(tag):]: z[k] for k in z.files if k.startswith(tag)}
+    d["texels"] = [d["texels%d" % i] for i in range(d["materials"].shape[0])]
+    return d
+
+
+def test_quirk_file_parses_like_the_reference(tmp_path):
+    ref = _golden("quirk_")
+    mine = _dump(QUIRK, tmp_path)
+    _compare(mine, ref, "quirk")
+    # the quirks really are in the golden: 5 faces from 5 `f` lines (one with four corners), the blank-led vertex line ignored,
+    # the Ks line with a '#' dropped (Ks stays 0), unknown usemtl -> material 0, light radiance attached by name
+    assert ref["vertex"].shape == (5, 3) and ref["face"].shape == (5, 3, 4)
+    assert np.array_equal(ref["face"][1, :, :3], [[0, 1, 2], [2, 0, 1], [3, 2, 0]])          # a/b/c with b != c
+    assert not ref["materials"][0, :3].any() and ref["materials"][0, 6] == 25
+    assert np.array_equal(ref["face"][3, :, 3], [0, 0, 0]) and np.array_equal(ref["materials"][3, 8:11], [10, 8.5, 6])
+    assert int(ref["materials"][2, 11]) == 0 and int(ref["materials"][1, 11]) == 12            # null Map_Kd; the 4x3 PNG
+
+
+def test_wavefront_order_swaps_the_two_attribute_indices(tmp_path):
+    a = _dump(QUIRK, tmp_path, ref_order=True)["face"]; b = _dump(QUIRK, tmp_path, ref_order=False)["face"]
+    assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 1], b[..., 2]) and np.array_equal(a[..., 2], b[..., 1])
+
+
+def test_generated_scene_files_parse_like_the_reference(pkg, tmp_path):
+    """OBJ + MTL + XML + four binary-PPM textures as scenes.py writes them (what every reference run in this repo loads)."""
+    obj = pkg.scenes.bathroom_stress(64, 36, detail=12, tex_size=32).write(str(tmp_path / "scene"))
+    _compare(_dump(obj, tmp_path), _golden("bath_"), "bath")
+
+
+def test_live_against_the_compiled_reference(pkg, orc, tmp_path):
+    try:
+        ref = orc.Reference()
+    except orc.ReferenceUnavailable:
+        pytest.skip("oracle/_ref not built here")
+    for obj in (QUIRK, pkg.scenes.cornell_box_small(32, 32).write(str(tmp_path / "cs")), pkg.scenes.veach_mis(32, 18, light_lon=8, light_lat=4, plate_cells=2).write(str(tmp_path / "vm"))):
+        m = ref.parse_model(obj)
+        m["size"] = np.array([m["width"], m["height"]])
+        _compare(_dump(obj, tmp_path), m, obj)
