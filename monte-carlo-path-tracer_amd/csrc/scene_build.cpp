@@ -373,13 +373,19 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     auto t0 = std::chrono::steady_clock::now();
     out.nodes.clear();
     std::vector<int> order;
+    bool built = false;
     if (custom_bvh && nf > uint32_t(MCPT_LEAF_MAX)) {
         std::vector<float> boxes(6 * size_t(nf));
         for (uint32_t f = 0; f < nf; f++)
             for (int a = 0; a < 3; a++) { boxes[6 * size_t(f) + a] = round_down(bt[f].lo[a], 0.f); boxes[6 * size_t(f) + 3 + a] = round_up(bt[f].hi[a], 0.f); }
         if (!custom_bvh(boxes.data(), nf, out.nodes, order, out.bvh_depth, out.max_leaf, err)) return MCPT_ERR_HIP;
         if (order.size() != nf || out.nodes.empty() || out.nodes.size() % 4 != 0) { err = "custom BVH builder returned inconsistent arrays"; return MCPT_ERR_HIP; }
-    } else {
+        // A Morton-code tree over many coincident centroids can come out deeper than the binary-tree kernels' stack: such a scene
+        // is rebuilt by the depth-capped host builder instead of being refused.
+        built = out.bvh_depth <= uint32_t(MCPT_STACK_DEPTH - 1);
+        if (!built) { out.nodes.clear(); order.clear(); }
+    }
+    if (!built) {
         Builder b(bt, out.nodes);
         b.run();
         if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] SAH %.0f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

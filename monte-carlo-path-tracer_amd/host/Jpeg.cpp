@@ -148,7 +148,7 @@ private:
         return true;
     }
     bool read_sos() {
-        size_t b, e; if (!segment(b, e) || width_ == 0) return false;
+        size_t b, e; if (!segment(b, e) || width_ == 0 || e - b < 1) return false;   // an empty SOS payload has no component count to read
         const int ns = d_[b];
         if (ns != ncomp_ || e - b < size_t(1 + 2 * ns + 3)) return false;   // baseline files carry one interleaved scan
         for (int i = 0; i < ns; i++) {
@@ -199,6 +199,7 @@ private:
         const int t = decode_symbol(dc_[c.td]);
         if (t < 0 || t > 11) return false;
         c.pred += extend(get_bits(t), t);
+        if (c.pred < -32768 || c.pred > 32767) return false;           // DC predictor outside the 16-bit range T.81 allows: a crafted / corrupt stream
         coef[0] = c.pred * qt_[c.tq][0];
         for (int k = 1; k < 64;) {
             const int rs = decode_symbol(ac_[c.ta]);

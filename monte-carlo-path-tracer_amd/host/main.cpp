@@ -1,6 +1,7 @@
 // mcpt_cli -- headless replacement for the reference's GLFW shell (src/main.cpp:4-39): load a scene, render N frames
 // (= spp), print the reference's per-frame line, save <name><frames>.png.  `--gpus N` shards the sample range over N
 // devices of this node from ONE process and sums the films with RCCL (ncclAllReduce over xGMI).
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -105,7 +106,9 @@ int main(int argc, char** argv) {
     }
     uint32_t frame = 0; uint64_t rays = 0; double total_s = 0;
     std::vector<float> film(size_t(w) * h * 4);
-    while (frame < spp) {
+    std::atomic<int> failed{0};                       // any device error or failed collective: no image, non-zero exit
+    auto fail_with = [&](const std::string& what) { std::cerr << "Error: " << what << std::endl; failed.store(1); };
+    while (frame < spp && !failed.load()) {
         const uint32_t n = std::min(batch, spp - frame);
         auto t0 = std::chrono::steady_clock::now();
         // sample range [frame, frame+n) split contiguously over the devices; one host thread per device (mcpt_render blocks
@@ -114,28 +117,36 @@ int main(int argc, char** argv) {
         for (uint32_t g = 0; g < gpus; g++) th.emplace_back([&, g]() {
             const uint32_t lo = frame + uint32_t(uint64_t(n) * g / gpus), hi = frame + uint32_t(uint64_t(n) * (g + 1) / gpus);
             mcpt_ctx* c = renders[g]->handle();
-            mcpt_clear_accum(c);
-            if (hi > lo && mcpt_render(c, hi - lo, seed, lo) != MCPT_OK) std::cerr << "Error: " << mcpt_last_error() << std::endl;
-            mcpt_sync(c);
+            if (mcpt_clear_accum(c) != MCPT_OK) return fail_with(std::string("mcpt_clear_accum: ") + mcpt_last_error());
+            if (hi > lo && mcpt_render(c, hi - lo, seed, lo) != MCPT_OK) return fail_with(std::string("mcpt_render: ") + mcpt_last_error());
+            if (mcpt_sync(c) != MCPT_OK) return fail_with(std::string("mcpt_sync: ") + mcpt_last_error());
         });
         for (auto& t : th) t.join();
+        if (failed.load()) break;
         if (gpus > 1) {                               // the path's one exchange step: sum of the per-device films over xGMI
-            ncclGroupStart();
-            for (uint32_t g = 0; g < gpus; g++) {
-                void* p = nullptr; mcpt_accum_device_ptr(renders[g]->handle(), &p);
-                (void)hipSetDevice(int(g));
-                ncclAllReduce(p, p, size_t(w) * h * 4, ncclFloat, ncclSum, comms[g], nullptr);
+            bool ok = ncclGroupStart() == ncclSuccess;
+            for (uint32_t g = 0; g < gpus && ok; g++) {
+                void* p = nullptr;
+                ok = mcpt_accum_device_ptr(renders[g]->handle(), &p) == MCPT_OK && hipSetDevice(int(g)) == hipSuccess &&
+                     ncclAllReduce(p, p, size_t(w) * h * 4, ncclFloat, ncclSum, comms[g], nullptr) == ncclSuccess;
             }
-            ncclGroupEnd();
-            for (uint32_t g = 0; g < gpus; g++) { (void)hipSetDevice(int(g)); (void)hipDeviceSynchronize(); }
+            ok = (ncclGroupEnd() == ncclSuccess) && ok;
+            for (uint32_t g = 0; g < gpus && ok; g++) ok = hipSetDevice(int(g)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            if (!ok) { fail_with("RCCL all-reduce of the films failed"); break; }
         }
-        mcpt_read_accum(renders[0]->handle(), film.data());
+        if (mcpt_read_accum(renders[0]->handle(), film.data()) != MCPT_OK) { fail_with(std::string("mcpt_read_accum: ") + mcpt_last_error()); break; }
         scene.add_film(film.data());
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         total_s += s; frame += n;
         std::cout << "frame: " << frame << "    frame cost: " << s << "s\n";                       // main.cpp:31
     }
-    for (uint32_t g = 0; g < gpus; g++) { mcpt_counters c; mcpt_get_counters(renders[g]->handle(), &c); rays += c.rays_primary + c.rays_continuation + c.rays_shadow; }
+    if (gpus > 1) for (auto& c : comms) (void)ncclCommDestroy(c);
+    if (failed.load()) { for (auto r : renders) delete r; return 1; }
+    for (uint32_t g = 0; g < gpus; g++) {
+        mcpt_counters c;
+        if (mcpt_get_counters(renders[g]->handle(), &c) != MCPT_OK) { std::cerr << "Error: " << mcpt_last_error() << std::endl; return 1; }
+        rays += c.rays_primary + c.rays_continuation + c.rays_shadow;
+    }
     std::printf("%u spp, %dx%d, %u GPU(s): %.3f s, %.1f Mray/s\n", spp, w, h, gpus, total_s, rays / total_s / 1e6);
     scene.save_image(int(frame), out);                                                              // main.cpp:37
     for (auto r : renders) delete r;

@@ -555,6 +555,27 @@ def test_cpp_cli_end_to_end(pkg, tmp_path):
     assert (np.abs(png.astype(int) - want.astype(int)) <= 1).mean() > 0.995   # host powf vs device powf at a rounding edge
 
 
+def test_cpp_cli_multi_gpu_path_or_its_failure(pkg, tmp_path):
+    """`mcpt_cli --gpus 2`: one process, one context per device, ncclCommInitAll + ncclAllReduce of the films (host/main.cpp).  On a node
+    with >= 2 GPUs the two-device film must equal the one-device film (same samples, summed once); on a one-GPU box the second context
+    cannot be created and the tool must say so, exit non-zero and write NO image (it used to print 'Image saved' after a failed device)."""
+    import subprocess
+    import torch
+    from PIL import Image
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "monte-carlo-path-tracer_amd", "csrc", "mcpt_cli")
+    obj = pkg.scenes.cornell_box_small(40, 32).write(str(tmp_path))
+    base = [cli, obj, "--spp", "8", "--depth", "4", "--seed", "5", "--deterministic"]
+    p2 = subprocess.run(base + ["--gpus", "2", "--out", str(tmp_path / "two")], capture_output=True, text=True)
+    if torch.cuda.device_count() >= 2:
+        assert p2.returncode == 0, p2.stderr
+        subprocess.check_call(base + ["--gpus", "1", "--out", str(tmp_path / "one")], stdout=subprocess.DEVNULL)
+        a = np.asarray(Image.open(str(tmp_path / "one8.png"))).astype(int); b = np.asarray(Image.open(str(tmp_path / "two8.png"))).astype(int)
+        assert (np.abs(a - b) <= 1).mean() > 0.999
+    else:
+        assert p2.returncode != 0 and "Error" in p2.stderr
+        assert not os.path.exists(str(tmp_path / "two8.png"))
+
+
 @pytest.mark.parametrize("name,kw,res,depth", [("veach-mis", {}, (1280, 720), 0), ("bathroom2", {"detail": 160}, (1920, 1080), 8)])
 def test_full_size_properties_other_configs(pkg, name, kw, res, depth):
     """configs[2] geometry (S-veach 1280x720, 3840 light triangles) and configs[3] geometry (S-bath 1920x1080, 0.59 M triangles,
