@@ -17,7 +17,7 @@ P2="SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VME
 P3="TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"
 P4="FETCH_SIZE"
 P5="WRITE_SIZE"
-i=0
+i=0; mkdir -p "$OUT/pmc"
 cd /tmp; export TMPDIR=/tmp
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
