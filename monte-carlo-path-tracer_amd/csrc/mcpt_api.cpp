@@ -217,7 +217,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 23);
         if (P < 2048) P = 2048;
         c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
-        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0);
+        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0); c->tune.pend_cap = env_u32("MCPT_WF_PEND", 48);
         c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0);
         if (c->use_wavefront) {
             uint32_t n_lanes = env_u32("MCPT_WF_LANES", 2);

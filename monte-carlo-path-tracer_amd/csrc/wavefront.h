@@ -52,6 +52,7 @@ struct WaveTuning {     // scheduler thresholds of the trace kernel (lanes out o
     uint32_t leaf_at;         // run the leaf block when at least this many lanes wait at a leaf
     uint32_t inner_keep;      // keep iterating the inner-node block while at least this many lanes are at inner nodes
     uint32_t policy;          // 0 = fixed thresholds above; 1 = greedy: run the block most lanes can take part in
+    uint32_t pend_cap;        // run the leaf block at the latest when this many lanes carry a parked leaf (speculative traversal)
 };
 
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,

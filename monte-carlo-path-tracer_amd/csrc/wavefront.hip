@@ -508,6 +508,17 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     float idx = 0, idy = 0, idz = 0, tmax = 0;
     int node = MCPT_NODE_SENTINEL, sp = 1;
+#ifndef WF_NO_POSTPONE
+    // Speculative traversal (Aila & Laine 2009): a lane that reaches a leaf parks it in `pend` and keeps descending; the leaf block tests
+    // the parked leaves of all lanes at once.  Invariant at the loop head: `node` is a leaf only while `pend` is occupied.  0 = none.
+    int pend = 0;
+#define WF_PEND pend
+#define WF_POP_NODE() { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = OVF(sp - WF_LDS_STACK); }
+#define WF_PARK_LEAF() if (pend == 0 && node < 0 && node != MCPT_NODE_SENTINEL) { pend = node; WF_POP_NODE() }
+#else
+#define WF_PEND 0
+#define WF_PARK_LEAF()
+#endif
     int htri = -1; float hu = 0, hv = 0;
     uint32_t n_box = 0, n_tri = 0, n_spill = 0;     // n_spill: stack entries that went to the global overflow area (COUNT builds)
 #ifdef WF_SCHED_STATS
@@ -521,9 +532,16 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 
     for (;;) {
         const bool at_inner = have && node >= 0;
+#ifndef WF_NO_POSTPONE
+        const bool at_leaf = have && pend != 0;                                    // has a parked leaf (may still be descending)
+        const int n_inner = __popcll(__ballot(at_inner)), n_pend = __popcll(__ballot(at_leaf));
+        const int n_leaf = __popcll(__ballot(at_leaf && node < 0));                // ... and cannot go on without it
+        const int n_idle = 64 - n_inner - n_leaf;
+#else
         const bool at_leaf = have && node < 0 && node != MCPT_NODE_SENTINEL;
         const int n_inner = __popcll(__ballot(at_inner)), n_leaf = __popcll(__ballot(at_leaf));
         const int n_idle = 64 - n_inner - n_leaf;
+#endif
 
         const int most = n_inner > n_leaf ? n_inner : n_leaf;
         if ((n_inner + n_leaf == 0) || (!exhausted && (greedy ? n_idle >= most : n_idle >= (int)tune.refill_at))) {
@@ -531,7 +549,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #ifdef WF_SCHED_STATS
             x_refill++; l_refill += (uint32_t)n_idle;
 #endif
-            if (have && node == MCPT_NODE_SENTINEL) {                    // finished: write the result back
+            if (have && node == MCPT_NODE_SENTINEL && WF_PEND == 0) {    // finished: write the result back
                 if (any) {                                               // Render.cpp:125-130: the verdict.  The next shade call adds the
                     if (blocked) st_s(reinterpret_cast<uint32_t*>(&pool.nee[slot]) + 3, 1u);   // ... NEE term it parked in pool.nee unless .w says "blocked"
                 } else {
@@ -588,19 +606,29 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
             continue;
         }
 
+#ifndef WF_NO_POSTPONE
+        if (n_leaf >= (int)tune.leaf_at || n_inner == 0 || n_pend >= (int)tune.pend_cap) {
+#else
         if ((greedy ? n_leaf >= n_inner : n_leaf >= (int)tune.leaf_at) || n_inner == 0) {
+#endif
             // ------------------------------------------------------------------ leaf block (all lanes waiting at a leaf)
 #ifdef WF_SCHED_STATS
             x_leaf++; if (at_leaf) n_tri++;
 #endif
             if (at_leaf) {
+#ifndef WF_NO_POSTPONE
+                const uint32_t leaf = (uint32_t)~pend;
+#else
                 const uint32_t leaf = (uint32_t)~node;
+#endif
                 const uint32_t first = leaf >> 3, cnt = leaf & 7u;
                 // The stack pop is requested BEFORE the triangle records, and a leaf's triangles are handled in pairs (a leaf of the SAH
                 // builder holds at most two).  The leaf block is 27 % of the waves' time at ~3 800 cycles per execution (tools/sched_stats.py).
+#ifdef WF_NO_POSTPONE
                 const int sp1 = sp - 1;
                 int popped;
                 if (sp1 < WF_LDS_STACK) popped = stk[sp1 * WF_TRACE_BLOCK]; else popped = OVF(sp1 - WF_LDS_STACK);
+#endif
                 bool done = false;
 #pragma unroll 1
                 for (uint32_t i = 0; i < cnt && !done; i += 2) {
@@ -631,8 +659,14 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                         else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = tb | __float_as_int(v0b.w); hu = r.u; hv = r.v; }
                     }
                 }
+#ifndef WF_NO_POSTPONE
+                pend = 0;
+                if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
+                else WF_PARK_LEAF()                                      // the lane was waiting AT another leaf: park that one now
+#else
                 if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
                 else { sp = sp1; node = popped; }
+#endif
             }
             WF_TICK(t_leaf)
             continue;
@@ -700,6 +734,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     if (key0 < inf) node = cd0;
                     else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = OVF(sp - WF_LDS_STACK); }
                 }
+                WF_PARK_LEAF()
             }
             if (greedy) {                                                  // stay while inner nodes are still what most lanes wait for
                 const int cl = __popcll(__ballot(have && node < 0 && node != MCPT_NODE_SENTINEL)), ci = __popcll(__ballot(have && node >= 0));
@@ -727,6 +762,11 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 }
 
 #undef OVF
+#undef WF_PEND
+#undef WF_PARK_LEAF
+#ifndef WF_NO_POSTPONE
+#undef WF_POP_NODE
+#endif
 // ====================================================================================================== launchers
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
                            float4* accum, DevCounters* cnt, hipStream_t stream) {
