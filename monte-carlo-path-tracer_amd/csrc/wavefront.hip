@@ -5,15 +5,17 @@
 // of the lanes own a shadow ray, and shading code inflates the traversal loop to 169 VGPRs (2 waves/SIMD).  Here the
 // path state lives in HBM (PathPool, 16-B records, one slot per lane => coalesced) and each iteration runs two kernels:
 //
-//   wf_shade_kernel  one lane per slot, every lane busy: consumes the hit of the slot's extend ray (emitter MIS, Russian
-//                    roulette, termination, film write, regeneration of the next camera ray) and produces the next
-//                    extend ray + at most one shadow ray (atomic-free queue: block b owns entries [256 b, 256 b + n)).
+//   wf_shade_kernel  branch-sorted: a 256-thread block loads its 256 slots' state into LDS, classifies the slots (finished / ends here /
+//                    diffuse / Phong / mirror), sorts the slot indices by class, and lane j processes slot perm[j] in LDS: consumes the
+//                    hit of the slot's extend ray (emitter MIS, Russian roulette, termination, film write, regeneration of the next camera
+//                    ray) and produces the next extend ray + at most one shadow ray (atomic-free queue of complete ray records: block b
+//                    owns entries [256 b, 256 b + n)); the slots' own lanes then store the changed records coalesced.  ~100 VGPRs.
 //   wf_trace_kernel  persistent waves over the ray list [P extend slots | per-block shadow queues]; closest-hit and any-hit
 //                    rays share one traversal loop over the 4-wide quantised tree.  Each wave schedules itself with
 //                    __ballot/__popcll: it runs the inner-node block while most lanes sit at inner nodes, the leaf block
-//                    once enough lanes wait at a leaf, and the refill block (write results back, pull fresh rays from a
-//                    wave-private chunk of the list) once enough lanes are idle -- so the expensive blocks execute with
-//                    well-packed lanes.  69 VGPRs; 1024-thread blocks with 64 KB of LDS (top tree levels + per-lane stack).
+//                    once enough lanes cannot go on without their (parked) leaf, and the refill block (write results back, pull fresh
+//                    rays from a wave-private chunk of the list) once enough lanes are idle -- so the expensive blocks execute with
+//                    well-packed lanes.  71 VGPRs; 1024-thread blocks with 64 KB of LDS (top tree levels + per-lane stack).
 // DESIGN.md §5 has the measurements behind each of these choices.
 #include "pt_device.h"
 #include "wavefront.h"
