@@ -198,6 +198,9 @@ mcpt_status mcpt_probe_sample_light(mcpt_ctx* ctx, uint32_t n, const double* poi
  * generator keyed (seed, pixel = item, sample = 0).  out: L[3].  Runs the production wavefront pipeline (wf_shade_kernel +
  * wf_trace_kernel over a path pool, item = entry of an n x 1 film); the cross-check megakernel only under MCPT_PIPELINE=mega. */
 mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, uint64_t seed, float* out_L3);
+/* Texture::get_color (model.cpp:30-41) of material `material`'s Map_Kd for n (u, v) pairs (fp32, as the device interpolates them):
+ * nearest texel, fract + clamp01's 0.999 cap, no v flip; a 1x1 texture returns its constant colour. */
+mcpt_status mcpt_probe_texture(mcpt_ctx* ctx, uint32_t material, uint32_t n, const float* uv2, float* out_rgb3);
 /* The generator itself: n*4 uniforms for (pixel, sample, block) triples -- pins oracle and device to one stream. */
 mcpt_status mcpt_probe_rng(mcpt_ctx* ctx, uint32_t n, const uint32_t* pixel_sample_block3, uint64_t seed, float* out4);
 

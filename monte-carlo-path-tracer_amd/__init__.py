@@ -104,7 +104,9 @@ class DescHolder:
         self.materials = (MaterialC * n)()
         self.textures = (Texture * n)()
         for i, m in enumerate(scene.materials):
-            if m.texture is not None:
+            if m.texture is not None and m.texture.dtype == np.float32:
+                t = np.ascontiguousarray(m.texture)               # already what stbi_loadf would return (tests feed reference texels)
+            elif m.texture is not None:
                 t = np.ascontiguousarray(texture_to_float(m.texture))
             else:  # Texture(Color3f kd): kd parsed with stof (model.cpp:189-193)
                 t = np.asarray(m.kd, np.float32).reshape(1, 1, 3).copy()
@@ -174,6 +176,7 @@ def load_library() -> C.CDLL:
         "mcpt_probe_sample_light": [vp, C.c_uint32, vp, vp, vp],
         "mcpt_probe_paths": [vp, C.c_uint32, vp, vp, C.c_uint64, vp],
         "mcpt_probe_rng": [vp, C.c_uint32, vp, C.c_uint64, vp],
+        "mcpt_probe_texture": [vp, C.c_uint32, C.c_uint32, vp, vp],
     }
     for name, args in sigs.items():
         if not hasattr(lib, name) and "MCPT_LIB_PATH" in os.environ:
@@ -192,7 +195,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_render", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap",
     "mcpt_get_counters", "mcpt_reset_counters", "mcpt_bind_accum", "mcpt_accum_device_ptr", "mcpt_set_stream",
     "mcpt_set_null_stream", "mcpt_probe_trace", "mcpt_probe_trace4", "mcpt_probe_cast_ray", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
-    "mcpt_probe_paths", "mcpt_probe_rng",
+    "mcpt_probe_paths", "mcpt_probe_rng", "mcpt_probe_texture",
 ]
 
 
@@ -343,6 +346,12 @@ class Renderer:
         o = np.ascontiguousarray(origin, np.float64).reshape(-1, 3); d = np.ascontiguousarray(direction, np.float64).reshape(-1, 3)
         out = np.zeros((o.shape[0], 3), np.float32)
         self._check(self.lib.mcpt_probe_paths(self.ctx, o.shape[0], _ptr(o), _ptr(d), seed, _ptr(out)))
+        return out
+
+    def probe_texture(self, material, uv):
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((uv.shape[0], 3), np.float32)
+        self._check(self.lib.mcpt_probe_texture(self.ctx, material, uv.shape[0], _ptr(uv), _ptr(out)))
         return out
 
     def probe_rng(self, pixel_sample_block, seed=0):

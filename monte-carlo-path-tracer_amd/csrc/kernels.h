@@ -12,4 +12,5 @@ hipError_t launch_probe_cast_ray(const DevScene& sc, uint32_t n, const int* xy, 
 hipError_t launch_probe_bsdf(uint32_t n, const float* normal, const float* wi, const float* kd, const float* ks, const float* ns, const float* wo,
                              const float* xi, float* out12, hipStream_t stream);
 hipError_t launch_probe_sample_light(const DevScene& sc, uint32_t n, const double* point, const float* xi, float* out10, hipStream_t stream);
+hipError_t launch_probe_texture(const DevScene& sc, int material, uint32_t n, const float* uv, float* out3, hipStream_t stream);
 hipError_t launch_probe_rng(uint32_t n, const uint32_t* key3, uint32_t seed_lo, uint32_t seed_hi, float* out4, hipStream_t stream);

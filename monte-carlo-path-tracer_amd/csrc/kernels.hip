@@ -344,6 +344,14 @@ __global__ void probe_sample_light_kernel(DevScene sc, uint32_t n, const double*
     o[8] = (float)sc.tri_face[ls.tri]; o[9] = ls.self_hit ? 1.f : 0.f;
 }
 
+__global__ void probe_texture_kernel(DevScene sc, int material, uint32_t n, const float* uv, float* out3) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t fetches = 0;
+    const f3 c = tex_color(sc, sc.mats[material], uv[2 * i], uv[2 * i + 1], fetches);
+    out3[3 * i] = c.x; out3[3 * i + 1] = c.y; out3[3 * i + 2] = c.z;
+}
+
 __global__ void probe_rng_kernel(uint32_t n, const uint32_t* key3, uint32_t seed_lo, uint32_t seed_hi, float* out4) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -391,6 +399,10 @@ hipError_t launch_probe_bsdf(uint32_t n, const float* normal, const float* wi, c
 }
 hipError_t launch_probe_sample_light(const DevScene& sc, uint32_t n, const double* point, const float* xi, float* out10, hipStream_t stream) {
     hipLaunchKernelGGL(probe_sample_light_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, point, xi, out10);
+    return hipGetLastError();
+}
+hipError_t launch_probe_texture(const DevScene& sc, int material, uint32_t n, const float* uv, float* out3, hipStream_t stream) {
+    hipLaunchKernelGGL(probe_texture_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, material, n, uv, out3);
     return hipGetLastError();
 }
 hipError_t launch_probe_rng(uint32_t n, const uint32_t* key3, uint32_t seed_lo, uint32_t seed_hi, float* out4, hipStream_t stream) {

@@ -720,6 +720,19 @@ mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, co
     return MCPT_OK;
 }
 
+mcpt_status mcpt_probe_texture(mcpt_ctx* ctx, uint32_t material, uint32_t n, const float* uv2, float* out_rgb3) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!uv2 || !out_rgb3) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (material >= uint32_t(ctx->dev.n_mats)) return fail(MCPT_ERR_INVALID_ARG, "material index out of range");
+    if (n == 0) return MCPT_OK;
+    Scratch s; float *d_uv, *d_out;
+    HIP_TRY(s.in(uv2, 2 * size_t(n), &d_uv)); HIP_TRY(s.out(3 * size_t(n), &d_out));
+    HIP_TRY(launch_probe_texture(ctx->dev, int(material), n, d_uv, d_out, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out_rgb3, d_out, 3 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
 mcpt_status mcpt_probe_rng(mcpt_ctx* ctx, uint32_t n, const uint32_t* key3, uint64_t seed, float* out4) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
     if (!key3 || !out4) return fail(MCPT_ERR_INVALID_ARG, "null argument");
