@@ -15,3 +15,6 @@ struct GpuBvh {
 
 // Needs n > MCPT_LEAF_MAX and a current HIP device.  Returns false with `err` set on any HIP error.
 bool gpu_build_bvh2(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string& err);
+// Same contract, SAH-costed: PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) over the Morton order -- every merge is
+// the one that minimises the merged box's surface area within a +-16 window.  The default of MCPT_FLAG_GPU_BVH_BUILD.
+bool gpu_build_ploc(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string& err);

@@ -12,8 +12,8 @@
 //
 // Everything downstream (breadth-first renumbering, collapse to the 4-wide quantised tree, triangle streams in leaf order) is the
 // same host code that follows the SAH builder.  Traversal results do not depend on the tree (closest hit = min t), only its cost
-// does: LBVH trees cost ~1.2-1.5x the SAH tree's node visits, so the SAH builder stays the default and this one is opt-in
-// (MCPT_FLAG_GPU_BVH_BUILD).
+// does: LBVH trees cost ~1.3x the SAH tree's node visits (S-bath 0.59 M: +17 % render time), so MCPT_FLAG_GPU_BVH_BUILD uses the
+// SAH-costed PLOC builder further down (gpu_build_ploc: +4 %) and this one is kept behind MCPT_GPU_BVH=lbvh.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -171,9 +171,170 @@ __global__ void emit_kernel(const float* __restrict__ boxes, const uint32_t* __r
     o[3] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), 0.f, 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------- PLOC (SAH-costed agglomeration)
+// Parallel locally-ordered clustering (Meister & Bittner 2018) over the Morton-sorted triangles: every cluster looks PLOC_RADIUS
+// positions to either side for the partner that minimises the SURFACE AREA of the merged box (the SAH's cost term), mutual nearest
+// neighbours merge, the array is compacted, repeat until one cluster is left.  Unlike the Karras tree above, whose splits are the
+// bits of a space-filling curve, every merge here is chosen by area -- the tree quality of a sweep-SAH build at Morton-sort speed.
+#ifndef PLOC_RADIUS
+#define PLOC_RADIUS 16
+#endif
+__device__ __forceinline__ float half_area(const Box6& b) { const float x = b.hx - b.lx, y = b.hy - b.ly, z = b.hz - b.lz; return x * y + y * z + z * x; }
+
+__global__ void ploc_init_kernel(const float* __restrict__ boxes, const uint32_t* __restrict__ order, uint32_t n, Box6* __restrict__ cbox, uint32_t* __restrict__ cref) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cbox[i] = load_tri_box(boxes, order, i); cref[i] = LEAF_BIT | i;
+}
+// nearest neighbour within +-PLOC_RADIUS positions; the block's window of boxes is staged in LDS
+__global__ void __launch_bounds__(256) ploc_nn_kernel(const Box6* __restrict__ cbox, uint32_t nc, uint32_t* __restrict__ nn) {
+    __shared__ Box6 tile[256 + 2 * PLOC_RADIUS];
+    const int base = (int)(blockIdx.x * 256u) - PLOC_RADIUS;
+    for (int t = threadIdx.x; t < 256 + 2 * PLOC_RADIUS; t += 256) { const int g = base + t; if (g >= 0 && g < (int)nc) tile[t] = cbox[g]; }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nc) return;
+    const Box6 me = tile[threadIdx.x + PLOC_RADIUS];
+    float best = 3.4e38f; uint32_t bj = i;
+    for (int o = -PLOC_RADIUS; o <= PLOC_RADIUS; o++) {
+        const int g = (int)i + o;
+        if (o == 0 || g < 0 || g >= (int)nc) continue;
+        const float a = half_area(merge(me, tile[threadIdx.x + PLOC_RADIUS + o]));
+        if (a < best) { best = a; bj = (uint32_t)g; }                 // ties: the lower index, on both sides of a pair -> mutual
+    }
+    nn[i] = bj;
+}
+// mutual pairs merge into a new inner node (claimed from an atomic counter) at the lower position; the upper position dies
+__global__ void ploc_merge_kernel(const Box6* __restrict__ cbox, const uint32_t* __restrict__ cref, const uint32_t* __restrict__ nn, uint32_t nc,
+                                  uint32_t* __restrict__ node_count, uint32_t* __restrict__ left, uint32_t* __restrict__ right, Box6* __restrict__ nbox,
+                                  Box6* __restrict__ obox, uint32_t* __restrict__ oref, uint32_t* __restrict__ valid) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    const uint32_t j = nn[i];
+    if (j != i && nn[j] == i) {
+        if (i < j) {
+            const uint32_t k = atomicAdd(node_count, 1u);
+            const Box6 b = merge(cbox[i], cbox[j]);
+            left[k] = cref[i]; right[k] = cref[j]; nbox[k] = b;
+            obox[i] = b; oref[i] = k; valid[i] = 1u;
+        } else valid[i] = 0u;
+    } else { obox[i] = cbox[i]; oref[i] = cref[i]; valid[i] = 1u; }
+}
+__global__ void ploc_compact_kernel(const Box6* __restrict__ obox, const uint32_t* __restrict__ oref, const uint32_t* __restrict__ valid,
+                                    const uint32_t* __restrict__ pos, uint32_t nc, Box6* __restrict__ cbox, uint32_t* __restrict__ cref) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc || !valid[i]) return;
+    cbox[pos[i]] = obox[i]; cref[pos[i]] = oref[i];
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return false; } } while (0)
 
 }  // namespace
+
+bool gpu_build_ploc(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string& err) {
+    if (n <= (uint32_t)MCPT_LEAF_MAX) { err = "gpu_build_ploc: needs more than MCPT_LEAF_MAX triangles"; return false; }
+    const auto t0 = std::chrono::steady_clock::now();
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) {
+            const float c = 0.5f * (tri_boxes[6 * (size_t)i + a] + tri_boxes[6 * (size_t)i + 3 + a]);
+            if (!(c == c) || std::fabs(c) > 3.0e38f) { err = "gpu_build_ploc: non-finite triangle bounds"; return false; }
+            lo[a] = std::fmin(lo[a], c); hi[a] = std::fmax(hi[a], c);
+        }
+    const float3 dlo = make_float3(lo[0], lo[1], lo[2]);
+    const float3 inv = make_float3(hi[0] > lo[0] ? 1.f / (hi[0] - lo[0]) : 0.f, hi[1] > lo[1] ? 1.f / (hi[1] - lo[1]) : 0.f, hi[2] > lo[2] ? 1.f / (hi[2] - lo[2]) : 0.f);
+    const uint32_t ni = n - 1;
+    DBuf d_boxes, d_k0, d_k1, d_v0, d_v1, d_left, d_right, d_nbox, d_cb0, d_cb1, d_cr0, d_cr1, d_nn, d_valid, d_pos, d_cnt, d_tmp;
+    CK(d_boxes.alloc(sizeof(float) * 6 * (size_t)n));
+    CK(d_k0.alloc(8 * (size_t)n)); CK(d_k1.alloc(8 * (size_t)n)); CK(d_v0.alloc(4 * (size_t)n)); CK(d_v1.alloc(4 * (size_t)n));
+    CK(d_left.alloc(4 * (size_t)ni)); CK(d_right.alloc(4 * (size_t)ni)); CK(d_nbox.alloc(sizeof(Box6) * (size_t)ni));
+    CK(d_cb0.alloc(sizeof(Box6) * (size_t)n)); CK(d_cb1.alloc(sizeof(Box6) * (size_t)n)); CK(d_cr0.alloc(4 * (size_t)n)); CK(d_cr1.alloc(4 * (size_t)n));
+    CK(d_nn.alloc(4 * (size_t)n)); CK(d_valid.alloc(4 * (size_t)n)); CK(d_pos.alloc(4 * (size_t)n)); CK(d_cnt.alloc(4));
+    CK(hipMemcpy(d_boxes.p, tri_boxes, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
+    CK(hipMemset(d_cnt.p, 0, 4));
+    const int B = 256;
+    hipLaunchKernelGGL(morton_kernel, dim3((n + B - 1) / B), dim3(B), 0, 0, d_boxes.as<float>(), n, dlo, inv, d_k0.as<uint64_t>(), d_v0.as<uint32_t>());
+    CK(hipGetLastError());
+    size_t tmp_bytes = 0, scan_bytes = 0;
+    CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint32_t>(), d_v1.as<uint32_t>(), (size_t)n, 0u, 63u));
+    CK(rocprim::exclusive_scan(nullptr, scan_bytes, d_valid.as<uint32_t>(), d_pos.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>()));
+    CK(d_tmp.alloc(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes));
+    CK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_v0.as<uint32_t>(), d_v1.as<uint32_t>(), (size_t)n, 0u, 63u));
+    const uint32_t* order = d_v1.as<uint32_t>();
+    hipLaunchKernelGGL(ploc_init_kernel, dim3((n + B - 1) / B), dim3(B), 0, 0, d_boxes.as<float>(), order, n, d_cb0.as<Box6>(), d_cr0.as<uint32_t>());
+    CK(hipGetLastError());
+    uint32_t nc = n, iterations = 0;
+    while (nc > 1) {
+        const dim3 g((nc + B - 1) / B);
+        hipLaunchKernelGGL(ploc_nn_kernel, g, dim3(B), 0, 0, d_cb0.as<Box6>(), nc, d_nn.as<uint32_t>());
+        hipLaunchKernelGGL(ploc_merge_kernel, g, dim3(B), 0, 0, d_cb0.as<Box6>(), d_cr0.as<uint32_t>(), d_nn.as<uint32_t>(), nc, d_cnt.as<uint32_t>(), d_left.as<uint32_t>(),
+                           d_right.as<uint32_t>(), d_nbox.as<Box6>(), d_cb1.as<Box6>(), d_cr1.as<uint32_t>(), d_valid.as<uint32_t>());
+        CK(hipGetLastError());
+        CK(rocprim::exclusive_scan(d_tmp.p, scan_bytes, d_valid.as<uint32_t>(), d_pos.as<uint32_t>(), 0u, (size_t)nc, rocprim::plus<uint32_t>()));
+        hipLaunchKernelGGL(ploc_compact_kernel, g, dim3(B), 0, 0, d_cb1.as<Box6>(), d_cr1.as<uint32_t>(), d_valid.as<uint32_t>(), d_pos.as<uint32_t>(), nc, d_cb0.as<Box6>(),
+                           d_cr0.as<uint32_t>());
+        CK(hipGetLastError());
+        uint32_t lp = 0, lv = 0;
+        CK(hipMemcpy(&lp, d_pos.as<uint32_t>() + (nc - 1), 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&lv, d_valid.as<uint32_t>() + (nc - 1), 4, hipMemcpyDeviceToHost));
+        const uint32_t next = lp + lv;
+        if (next >= nc) { err = "gpu_build_ploc: no pair merged (internal error)"; return false; }
+        nc = next;
+        if (++iterations > 4096) { err = "gpu_build_ploc: did not converge"; return false; }
+    }
+    uint32_t made = 0, root_ref = 0;
+    CK(hipMemcpy(&made, d_cnt.p, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&root_ref, d_cr0.p, 4, hipMemcpyDeviceToHost));
+    if (made != ni || (root_ref & LEAF_BIT)) { err = "gpu_build_ploc: inconsistent node count"; return false; }
+    // ---- host: depth-first emission.  Subtrees of <= MCPT_LEAF_MAX triangles become leaves, leaf order = depth-first order (so every
+    //      leaf's triangles are contiguous), inner nodes are written in the host builder's 64-B format (child boxes in the parent).
+    std::vector<uint32_t> left(ni), right(ni), sorted(n); std::vector<Box6> nbox(ni); std::vector<float> hboxes;
+    CK(hipMemcpy(left.data(), d_left.p, 4 * (size_t)ni, hipMemcpyDeviceToHost)); CK(hipMemcpy(right.data(), d_right.p, 4 * (size_t)ni, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(nbox.data(), d_nbox.p, sizeof(Box6) * (size_t)ni, hipMemcpyDeviceToHost)); CK(hipMemcpy(sorted.data(), order, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> size(ni, 0);
+    {   // nodes are created children-first (a merge refers only to existing clusters): one forward pass gives the subtree sizes
+        for (uint32_t k = 0; k < ni; k++) {
+            const uint32_t l = left[k], r = right[k];
+            size[k] = ((l & LEAF_BIT) ? 1u : size[l]) + ((r & LEAF_BIT) ? 1u : size[r]);
+        }
+    }
+    auto tri_box = [&](uint32_t pos) { const float* b = tri_boxes + 6 * (size_t)sorted[pos]; return Box6{b[0], b[1], b[2], b[3], b[4], b[5]}; };
+    auto ref_size = [&](uint32_t ref) { return (ref & LEAF_BIT) ? 1u : size[ref]; };
+    auto ref_box = [&](uint32_t ref) { return (ref & LEAF_BIT) ? tri_box(ref & ~LEAF_BIT) : nbox[ref]; };
+    out.nodes.clear(); out.nodes.reserve(4 * (size_t)ni); out.order.clear(); out.order.reserve(n);
+    uint32_t depth = 0, max_leaf = 0;
+    struct Item { uint32_t ref; int parent_out; int which; uint32_t depth; };
+    std::vector<Item> stack; stack.push_back({root_ref, -1, 0, 1});
+    std::vector<uint32_t> leaf_tris;
+    auto pad_box = [](Box6 b) {
+        const float m = std::fmax(std::fmax(std::fmax(std::fabs(b.lx), std::fabs(b.hx)), std::fmax(std::fabs(b.ly), std::fabs(b.hy))), std::fmax(std::fabs(b.lz), std::fabs(b.hz)));
+        const float pad = m * 1e-6f + 1e-30f;
+        b.lx -= pad; b.ly -= pad; b.lz -= pad; b.hx += pad; b.hy += pad; b.hz += pad; return b;
+    };
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        int code;
+        if (ref_size(it.ref) <= (uint32_t)MCPT_LEAF_MAX) {                       // leaf: collect its triangles in order
+            leaf_tris.clear();
+            uint32_t st[2 * MCPT_LEAF_MAX + 2]; int sp = 0; st[sp++] = it.ref;      // a subtree of <= MCPT_LEAF_MAX triangles: tiny fixed stack
+            while (sp > 0) { const uint32_t r = st[--sp]; if (r & LEAF_BIT) leaf_tris.push_back(sorted[r & ~LEAF_BIT]); else { st[sp++] = right[r]; st[sp++] = left[r]; } }
+            code = ~(int)(((uint32_t)out.order.size() << 3) | (uint32_t)leaf_tris.size());
+            for (uint32_t t : leaf_tris) out.order.push_back(t);
+            max_leaf = std::max<uint32_t>(max_leaf, (uint32_t)leaf_tris.size());
+        } else {
+            code = (int)(out.nodes.size() / 4);
+            depth = std::max(depth, it.depth);
+            const Box6 b0 = pad_box(ref_box(left[it.ref])), b1 = pad_box(ref_box(right[it.ref]));
+            out.nodes.push_back({b0.lx, b0.hx, b0.ly, b0.hy}); out.nodes.push_back({b1.lx, b1.hx, b1.ly, b1.hy});
+            out.nodes.push_back({b0.lz, b0.hz, b1.lz, b1.hz}); out.nodes.push_back({0.f, 0.f, 0.f, 0.f});
+            stack.push_back({right[it.ref], code, 1, it.depth + 1});              // left is popped (emitted) first
+            stack.push_back({left[it.ref], code, 0, it.depth + 1});
+        }
+        if (it.parent_out >= 0) { f4h& c = out.nodes[4 * (size_t)it.parent_out + 3]; float f; std::memcpy(&f, &code, 4); if (it.which == 0) c.x = f; else c.y = f; }
+    }
+    if (out.order.size() != n || out.nodes.empty()) { err = "gpu_build_ploc: emission lost triangles"; return false; }
+    out.depth = depth; out.max_leaf = max_leaf;
+    out.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
 
 bool gpu_build_bvh2(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string& err) {
     if (n <= (uint32_t)MCPT_LEAF_MAX) { err = "gpu_build_bvh2: needs more than MCPT_LEAF_MAX triangles"; return false; }

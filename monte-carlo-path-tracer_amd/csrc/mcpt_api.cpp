@@ -173,7 +173,9 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         st = build_host_scene(scene, hs, err, [&](const float* boxes, uint32_t n, std::vector<f4h>& nodes, std::vector<int>& order, uint32_t& depth,
                                                    uint32_t& max_leaf, std::string& berr) {
             GpuBvh g;
-            if (!gpu_build_bvh2(boxes, n, g, berr)) return false;
+            const char* kind = std::getenv("MCPT_GPU_BVH");                        // developer knob: "lbvh" = the plain Karras tree
+            const bool lbvh = kind && std::string(kind) == "lbvh";
+            if (!(lbvh ? gpu_build_bvh2(boxes, n, g, berr) : gpu_build_ploc(boxes, n, g, berr))) return false;
             nodes.swap(g.nodes); order.assign(g.order.begin(), g.order.end()); depth = g.depth; max_leaf = g.max_leaf;
             return true;
         });

@@ -106,3 +106,31 @@ def test_device_builder_is_faster_on_a_large_scene(pkg):
     print("\nBVH build, %d triangles: host SAH %.0f ms (depth %d, %d nodes) | device LBVH %.0f ms (depth %d, %d nodes)" % (
         ih.n_tris, ih.bvh_build_ms, ih.bvh_depth, ih.n_nodes, ig.bvh_build_ms, ig.bvh_depth, ig.n_nodes))
     assert ig.bvh_build_ms < ih.bvh_build_ms
+
+
+@pytest.mark.parametrize("kind", ["lbvh", "ploc"])
+def test_both_device_builders_are_sound_and_ploc_is_the_better_tree(pkg, paths, kind):
+    """MCPT_FLAG_GPU_BVH_BUILD builds a SAH-costed tree by default (PLOC: every merge minimises the merged box's area within a +-16
+    window of the Morton order); MCPT_GPU_BVH=lbvh keeps the plain Karras tree.  Both must pass the soundness walk and return the
+    reference's hits through the production kernel; the PLOC tree must cost fewer box tests per ray than the LBVH and stay within
+    15 % of the host's binned-SAH tree (measured on S-bath detail 24: host 1.00, PLOC ~1.0, LBVH ~1.3)."""
+    os.environ["MCPT_GPU_BVH"] = kind
+    try:
+        r = _gpu_tree_renderer(pkg, pkg.scenes.cornell_box_small(64, 64))
+        t, tri, u, v = r.probe_trace4(paths["cs_ray_o"], paths["cs_ray_d"]); r.close()
+        ref_tri = paths["cs_ray_rec"][:, 11].astype(np.int32); ref_hit = paths["cs_ray_hit"] == 1
+        assert (tri == np.where(ref_hit, ref_tri, -1)).mean() >= 0.999
+        scene = pkg.scenes.bathroom_stress(96, 54, detail=24, tex_size=32)
+        cost = {}
+        for name, fl in (("host", 0), (kind, pkg.FLAG_GPU_BVH_BUILD)):
+            rr = pkg.Renderer(scene, max_depth=6, flags=fl | pkg.FLAG_COUNT_TRAVERSAL | pkg.FLAG_CORRECT_SHADOW_T2)
+            rr.render(8, seed=3); c = rr.counters(); i = rr.info(); rr.close()
+            cost[name] = c.box_tests / c.rays
+            assert i.bvh_depth <= 63
+        print(kind, "box tests per ray: host %.1f device %.1f" % (cost["host"], cost[kind]))
+        if kind == "ploc":
+            assert cost["ploc"] <= 1.15 * cost["host"]
+        else:
+            assert cost["lbvh"] <= 2.0 * cost["host"]
+    finally:
+        os.environ.pop("MCPT_GPU_BVH", None)
