@@ -18,3 +18,7 @@ bool gpu_build_bvh2(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string
 // Same contract, SAH-costed: PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) over the Morton order -- every merge is
 // the one that minimises the merged box's surface area within a +-16 window.  The default of MCPT_FLAG_GPU_BVH_BUILD.
 bool gpu_build_ploc(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string& err);
+
+// The 4-wide collapse + 8-bit quantisation of build_bvh4 (scene_build.cpp) on the device, level by level: binary nodes in (host builder's
+// layout, root = node 0), nodes4 out (device_scene.h layout, breadth-first by level), plus the depth of the 4-wide tree.
+bool gpu_collapse_bvh4(const std::vector<f4h>& nodes2, std::vector<f4h>& nodes4, uint32_t& depth4, std::string& err);

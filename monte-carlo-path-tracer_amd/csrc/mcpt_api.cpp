@@ -62,6 +62,7 @@ struct mcpt_ctx {
     uint32_t time_kernels = 0;          // MCPT_TIME_KERNELS=N: bracket the two kernels of every Nth iteration with HIP events (0 = off)
     double last_trace_ms = 0.0, total_trace_ms = 0.0, last_shade_ms = 0.0, total_shade_ms = 0.0;
     uint64_t total_iterations = 0;
+    bool binary_ok = true;                // the binary cross-check tree fits its kernels' stack (false: a deep device-built tree)
     std::vector<int32_t> h_tri_face;      // leaf order -> face index, fetched on first use by mcpt_probe_trace4
 };
 
@@ -170,6 +171,12 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if (o.flags & MCPT_FLAG_GPU_BVH_BUILD) {                              // the tree is built on the device the context will render on
         if ((st = check_device()) != MCPT_OK) return st;
         if ((e = hipSetDevice(o.device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
+        {   // An agglomerative (PLOC) tree over millions of triangles can be deeper than the binary-tree kernels' 64-entry stack.  Only the
+            // cross-check kernels (megakernel, recursive integrator, mcpt_probe_trace) walk the binary tree; the wavefront pipeline walks
+            // the 4-wide collapse of it, whose stack is sized from its own depth -- so a wavefront-only context keeps the deep tree.
+            const char* pipe = std::getenv("MCPT_PIPELINE");
+            hs.allow_deep_binary = !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS;
+        }
         st = build_host_scene(scene, hs, err, [&](const float* boxes, uint32_t n, std::vector<f4h>& nodes, std::vector<int>& order, uint32_t& depth,
                                                    uint32_t& max_leaf, std::string& berr) {
             GpuBvh g;
@@ -178,7 +185,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             if (!(lbvh ? gpu_build_bvh2(boxes, n, g, berr) : gpu_build_ploc(boxes, n, g, berr))) return false;
             nodes.swap(g.nodes); order.assign(g.order.begin(), g.order.end()); depth = g.depth; max_leaf = g.max_leaf;
             return true;
-        });
+        }, env_u32("MCPT_HOST_COLLAPSE", 0) ? Collapse4Fn(nullptr) : Collapse4Fn(gpu_collapse_bvh4));
         if (st != MCPT_OK) return fail(st, err);
         if (env_u32("MCPT_VALIDATE_BVH", 0)) { const std::string bad = validate_bvh4(hs); if (!bad.empty()) return fail(MCPT_ERR_HIP, "device-built BVH failed validation: " + bad); }
     } else {
@@ -272,6 +279,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     d.cam = hs.cam;
     d.n_tris = int32_t(hs.tri_face.size()); d.n_lights = int32_t(hs.lights.size()); d.n_nodes = int32_t(hs.nodes.size() / 4); d.n_mats = int32_t(hs.mats.size());
 
+    c->binary_ok = hs.binary_ok;
     mcpt_scene_info& in = c->info;
     in.n_tris = uint32_t(d.n_tris); in.n_lights = uint32_t(d.n_lights); in.n_nodes = uint32_t(d.n_nodes);
     in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
@@ -575,6 +583,7 @@ mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, co
                              float* out_t, int32_t* out_tri, float* out_u, float* out_v) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
     if (!origin || !dir || !t1 || !t2 || !out_t || !out_tri || !out_u || !out_v) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (!ctx->binary_ok) return fail(MCPT_ERR_BVH_DEPTH, "the binary cross-check tree of this (device-built) scene is deeper than its kernels' stack: use mcpt_probe_trace4");
     if (n == 0) return MCPT_OK;
     Scratch s; double *d_o, *d_d, *d_t1, *d_t2; float *d_t, *d_u, *d_v; int* d_tri;
     HIP_TRY(s.in(origin, 3 * size_t(n), &d_o)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.in(t1, n, &d_t1)); HIP_TRY(s.in(t2, n, &d_t2));

@@ -319,7 +319,7 @@ std::string validate_bvh4(const HostScene& hs) {
     return "";
 }
 
-mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh) {
+mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh, const Collapse4Fn& custom_collapse) {
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
     if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }
     if (d->camera.width <= 0 || d->camera.height <= 0) { err = "camera width/height must be positive"; return MCPT_ERR_INVALID_ARG; }
@@ -382,7 +382,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         if (order.size() != nf || out.nodes.empty() || out.nodes.size() % 4 != 0) { err = "custom BVH builder returned inconsistent arrays"; return MCPT_ERR_HIP; }
         // A Morton-code tree over many coincident centroids can come out deeper than the binary-tree kernels' stack: such a scene
         // is rebuilt by the depth-capped host builder instead of being refused.
-        built = out.bvh_depth <= uint32_t(MCPT_STACK_DEPTH - 1);
+        built = out.bvh_depth <= uint32_t(MCPT_STACK_DEPTH - 1) || (out.allow_deep_binary && out.bvh_depth <= 255u);
         if (!built) { out.nodes.clear(); order.clear(); }
     }
     if (!built) {
@@ -422,8 +422,12 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         out.nodes.swap(renum);
     }
     out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (out.bvh_depth > uint32_t(MCPT_STACK_DEPTH - 1)) { err = "BVH depth exceeds traversal stack"; return MCPT_ERR_BVH_DEPTH; }
-    build_bvh4(out);
+    out.binary_ok = out.bvh_depth <= uint32_t(MCPT_STACK_DEPTH - 1);
+    if (!out.binary_ok && !out.allow_deep_binary) { err = "BVH depth exceeds traversal stack"; return MCPT_ERR_BVH_DEPTH; }
+    if (custom_collapse) { if (!custom_collapse(out.nodes, out.nodes4, out.bvh4_depth, err)) return MCPT_ERR_HIP; }
+    else build_bvh4(out);
+    if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] 4-wide collapse done at %.0f ms (%zu nodes4, depth %u)\n",
+                                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), out.nodes4.size() / 4, out.bvh4_depth);
     std::vector<int> pos_of_face(nf);
     for (uint32_t i = 0; i < nf; i++) pos_of_face[order[i]] = int(i);
 

@@ -23,6 +23,8 @@ struct HostScene {
     std::vector<f4h> texels;
     DevCamera cam;
     uint32_t bvh_depth = 0, max_leaf = 0, bvh4_depth = 0;
+    bool allow_deep_binary = false;  // in: the caller never traverses `nodes` (wavefront pipeline only) -> a device tree deeper than MCPT_STACK_DEPTH is fine
+    bool binary_ok = true;           // out: `nodes` fits the binary-tree kernels' stack
     double bvh_build_ms = 0.0;
 };
 
@@ -31,9 +33,13 @@ struct HostScene {
 using BvhBuildFn = std::function<bool(const float* boxes, uint32_t n, std::vector<f4h>& nodes, std::vector<int>& order, uint32_t& depth,
                                       uint32_t& max_leaf, std::string& err)>;
 
+// Optional replacement for the host's 4-wide collapse + quantisation (bvh_gpu.hip): binary nodes (renumbered, root = 0) in, nodes4 + depth out.
+using Collapse4Fn = std::function<bool(const std::vector<f4h>& nodes2, std::vector<f4h>& nodes4, uint32_t& depth4, std::string& err)>;
+
 // Validates the description (indices in range, sizes non-zero), flattens faces, collects lights, builds the BVH.
 // Returns MCPT_OK or an error code with `err` filled.
-mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh = nullptr);
+mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh = nullptr,
+                             const Collapse4Fn& custom_collapse = nullptr);
 
 // Host-side soundness check of the quantised 4-wide tree (empty string = sound); run by mcpt_check_scene.
 std::string validate_bvh4(const HostScene& hs);

@@ -668,6 +668,36 @@ def test_c5_same_seed_vs_oracle_small_view(pkg, orc, c5_scene):
     assert abs(int(c.rays_continuation) - oc["rays_continuation"]) <= 0.01 * oc["rays_continuation"]
 
 
+def test_c5_device_built_tree_same_seed_vs_oracle(pkg, orc, c5_scene):
+    """The 4 M-triangle scene with the tree built ON THE DEVICE (PLOC over the Morton order + level-synchronous 4-wide collapse and
+    quantisation, MCPT_FLAG_GPU_BVH_BUILD): the binary tree comes out deeper than the cross-check kernels' 64-entry stack (69 levels),
+    which a wavefront-only context accepts -- the production kernel walks the 4-wide collapse (31 levels, stack sized from it) -- while
+    mcpt_probe_trace, which would walk the binary tree, refuses.  Same seed against the fp64 oracle through a 64x36 film."""
+    scene = c5_scene.with_resolution(64, 36)
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    spp = 8
+    os.environ["MCPT_VALIDATE_BVH"] = "1"                                  # host-side soundness walk of the device-made 4-wide tree
+    try:
+        r = pkg.Renderer(scene, max_depth=16, flags=flags | pkg.FLAG_GPU_BVH_BUILD | pkg.FLAG_COUNT_TRAVERSAL)
+    finally:
+        os.environ.pop("MCPT_VALIDATE_BVH", None)
+    info = r.info()
+    r.render(spp, seed=55); g = r.read_accum(); c = r.counters()
+    if info.bvh_depth > 63:
+        with pytest.raises(pkg.McptError, match="probe_trace4"):
+            r.probe_trace(np.array([[2.0, 1.5, 4.7]]), np.array([[0.0, 0.0, -1.0]]))
+    t4 = r.probe_trace4(np.array([[2.0, 1.5, 4.7]]), np.array([[0.0, 0.0, -1.0]]))
+    r.close()
+    assert t4[1][0] >= 0
+    cpu, oc, _ = orc.Oracle(scene, max_depth=16, flags=flags).render(spp, seed=55)
+    gm, cm = g[..., :3] / spp, cpu[..., :3] / spp
+    frac = _frac_beyond(gm, cm)
+    print("C5 device tree: binary depth %d, %d nodes; pixels beyond tolerance %.3f%%, box tests/ray %.1f, spills %d, bvh build %.0f ms" % (
+        info.bvh_depth, info.n_nodes, 100 * frac, c.box_tests / c.rays, c.stack_spills, info.bvh_build_ms))
+    assert np.all(g[..., 3] == spp) and frac <= 0.005
+    assert np.allclose(gm.mean((0, 1)), cm.mean((0, 1)), rtol=1e-4)
+
+
 def test_smoke_entry_point():
     import __graft_entry__ as ge
     ge.smoke()
