@@ -252,7 +252,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
                                   (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
                                   (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o};
                 for (int i = 0; i < 12; i++) {
-                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / MCPT_BLOCK) * sizeof(uint32_t) : size_t(P) * 16;
+                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : size_t(P) * 16;
                     if ((e = L.pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
                     if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
                     *dst[i] = L.pool_bufs[i].p;
@@ -357,7 +357,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
         r.p.chunks = (r.p.spp + r.p.samples_per_item - 1) / r.p.samples_per_item;
         r.n_items = p0.probe_n ? p0.probe_n : uint32_t(tiles * 64 * r.p.chunks);
         r.pool = ctx->lanes[k].pool;
-        const uint32_t want = uint32_t(((uint64_t(r.n_items) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
+        const uint32_t want = uint32_t(((uint64_t(r.n_items) + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK) * WF_SHADE_BLOCK);
         if (r.pool.P > want) r.pool.P = want;                              // small jobs: do not sweep idle slots
         r.active = true; n_active++;
     }
@@ -606,11 +606,11 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
     if (n == 0) return MCPT_OK;
     mcpt_ctx::WfLane& L = ctx->lanes[0];
     PathPool pool = L.pool;
-    const uint32_t P = uint32_t(((uint64_t(n) + MCPT_BLOCK - 1) / MCPT_BLOCK) * MCPT_BLOCK);
+    const uint32_t P = uint32_t(((uint64_t(n) + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK) * WF_SHADE_BLOCK);
     if (P > pool.P) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_trace4: more rays than pool slots");
     pool.P = P;
     std::vector<float> ro(4 * size_t(P), 0.f), rd(4 * size_t(P), 0.f), sd(4 * size_t(P), 0.f), hit(4 * size_t(P), 0.f);
-    std::vector<uint32_t> queue(P, 0u), qcount(P / MCPT_BLOCK, 0u);
+    std::vector<uint32_t> queue(P, 0u), qcount(P / WF_SHADE_BLOCK, 0u);
     const int32_t no_skip = -1; float no_skip_f; std::memcpy(&no_skip_f, &no_skip, 4);
     for (uint32_t i = 0; i < P; i++) {
         float* o4 = &ro[4 * size_t(i)]; float* d4 = &rd[4 * size_t(i)]; float* s4 = &sd[4 * size_t(i)];
@@ -620,7 +620,7 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
         if (any_hit) {
             s4[3] = t2[i] > 3.0e38 ? 3.0e38f : float(t2[i]);
             queue[i] = i;                                               // shade block b queues its own slots in order
-            qcount[i / MCPT_BLOCK]++;
+            qcount[i / WF_SHADE_BLOCK]++;
         } else { const uint32_t one = 1u; std::memcpy(&d4[3], &one, 4); }   // bit 0 of ray_d.w: "an extend ray is pending"
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -6,6 +6,9 @@
 #include <stdint.h>
 #include "device_scene.h"
 
+#ifndef WF_SHADE_BLOCK
+#define WF_SHADE_BLOCK 256        // threads (= pool slots) per shade workgroup: the unit of the class sort, of a shadow-queue region and of a trace chunk
+#endif
 #define SLOT_DEAD  0u   // no work item bound
 #define SLOT_ALIVE 1u   // a path is in flight; its extend ray was (or is about to be) traced
 #define SLOT_DRAIN 2u   // path ended in the same shade call that emitted its last shadow ray: finalise next call
@@ -40,11 +43,11 @@ struct IterCtl {        // indexed [iteration & 3]; shade(it) zeroes entry (it+1
     struct { uint32_t v; uint32_t pad[15]; } item_cursor[WF_ITEM_SHARDS];   // work-item cursors, one 64-B line each
 };
 
-// Work items are handed out in units of MCPT_BLOCK consecutive items; unit u belongs to shard u % WF_ITEM_SHARDS.
-// local index l of shard k  ->  global item ((l / MCPT_BLOCK) * WF_ITEM_SHARDS + k) * MCPT_BLOCK + l % MCPT_BLOCK
+// Work items are handed out in units of WF_SHADE_BLOCK consecutive items; unit u belongs to shard u % WF_ITEM_SHARDS.
+// local index l of shard k  ->  global item ((l / WF_SHADE_BLOCK) * WF_ITEM_SHARDS + k) * WF_SHADE_BLOCK + l % WF_SHADE_BLOCK
 __host__ __device__ inline uint32_t wf_shard_capacity(uint32_t n_items, uint32_t k) {
-    const uint32_t units = (n_items + MCPT_BLOCK - 1) / MCPT_BLOCK;
-    return units > k ? ((units - k + WF_ITEM_SHARDS - 1) / WF_ITEM_SHARDS) * MCPT_BLOCK : 0u;
+    const uint32_t units = (n_items + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK;
+    return units > k ? ((units - k + WF_ITEM_SHARDS - 1) / WF_ITEM_SHARDS) * WF_SHADE_BLOCK : 0u;
 }
 
 struct WaveTuning {     // scheduler thresholds of the trace kernel (lanes out of 64)

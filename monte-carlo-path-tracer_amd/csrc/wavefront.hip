@@ -84,17 +84,17 @@ __device__ __forceinline__ uint32_t wave_first(uint32_t v) { return __builtin_am
 #define K_DIFF 2u      // K_DIFF + lobe class (HIT_CLASS_*) = K_PHONG, K_MIRROR
 #define K_COUNT 5u
 template <bool COUNT>
-__global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_kernel(DevScene sc, RenderParams p, PathPool pool, IterCtl* ctl, uint32_t it, uint32_t n_items,
+__global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_kernel(DevScene sc, RenderParams p, PathPool pool, IterCtl* ctl, uint32_t it, uint32_t n_items,
                                                               float4* __restrict__ accum, DevCounters* gcnt) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t base = blockIdx.x * MCPT_BLOCK;                             // pool.P is a multiple of MCPT_BLOCK
+    const uint32_t base = blockIdx.x * WF_SHADE_BLOCK;                             // pool.P is a multiple of WF_SHADE_BLOCK
     if (base + tid == 0) { const uint32_t n = (it + 1) & 3; ctl->trace_head[n] = 0; ctl->any_active[n] = 0; }
-    __shared__ uint32_t s_wave_cnt[MCPT_BLOCK / 64];
+    __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base, s_sel;
     // the whole slot state of the block's 256-slot window, fetched coalesced in ONE batch by the slots' own lanes and handed to the
     // lanes that will process them through LDS: no dependent second round of (gathering) global loads after the sort ...
-    __shared__ float4 s_beta[MCPT_BLOCK], s_hit[MCPT_BLOCK], s_L[MCPT_BLOCK], s_rd[MCPT_BLOCK], s_nee[MCPT_BLOCK], s_ro[MCPT_BLOCK];
-    __shared__ uint4 s_ids[MCPT_BLOCK];
+    __shared__ float4 s_beta[WF_SHADE_BLOCK], s_hit[WF_SHADE_BLOCK], s_L[WF_SHADE_BLOCK], s_rd[WF_SHADE_BLOCK], s_nee[WF_SHADE_BLOCK], s_ro[WF_SHADE_BLOCK];
+    __shared__ uint4 s_ids[WF_SHADE_BLOCK];
     // ... and the way back: the processing lane leaves the slot's new records in LDS (each output record reuses the LDS cell of an
     // input record of the SAME slot, which only this lane read: no hazard), and after one barrier the slots' own lanes store them
     // coalesced.  Permuted lanes storing straight to the pool write partial 128-B lines from several waves: measured 1.5x (class
@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
 #define OUT_RAY_O 2u
 #define OUT_SHADOW 4u
 #define OUT_IDS 8u
-    __shared__ uint32_t s_perm[MCPT_BLOCK];
-    __shared__ uint32_t s_kcnt[K_COUNT * (MCPT_BLOCK / 64)];                   // [key][wave]: count, then exclusive prefix
+    __shared__ uint32_t s_perm[WF_SHADE_BLOCK];
+    __shared__ uint32_t s_kcnt[K_COUNT * (WF_SHADE_BLOCK / 64)];                   // [key][wave]: count, then exclusive prefix
     // Small scene tables staged in LDS once per block: every scattered global load costs vector-memory issue time whether its
     // lanes hit 2 distinct lines or 64.  Lights (record + fp64 corners) and materials are tiny in typical scenes; larger tables
     // fall back to global memory.
@@ -113,10 +113,10 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     __shared__ float4 s_lights[WF_LDS_LIGHTS * 4];
     __shared__ double s_light_pos[WF_LDS_LIGHTS * 9];
     const bool mats_lds = sc.n_mats <= WF_LDS_MATS, lights_lds = sc.n_lights <= WF_LDS_LIGHTS;
-    if (mats_lds) for (uint32_t i = tid; i < (uint32_t)sc.n_mats * 4; i += MCPT_BLOCK) s_mats[i] = reinterpret_cast<const float4*>(sc.mats)[i];
+    if (mats_lds) for (uint32_t i = tid; i < (uint32_t)sc.n_mats * 4; i += WF_SHADE_BLOCK) s_mats[i] = reinterpret_cast<const float4*>(sc.mats)[i];
     if (lights_lds) {
-        for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 4; i += MCPT_BLOCK) s_lights[i] = reinterpret_cast<const float4*>(sc.lights)[i];
-        for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 9; i += MCPT_BLOCK) s_light_pos[i] = sc.tri_pos64[9 * (size_t)sc.lights[i / 9].tri + i % 9];
+        for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 4; i += WF_SHADE_BLOCK) s_lights[i] = reinterpret_cast<const float4*>(sc.lights)[i];
+        for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 9; i += WF_SHADE_BLOCK) s_light_pos[i] = sc.tri_pos64[9 * (size_t)sc.lights[i / 9].tri + i % 9];
     }
 
     // ---- classification of the lane's OWN slot (coalesced): which branch will this slot take?
@@ -148,12 +148,12 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         for (uint32_t k = 0; k < K_COUNT; k++) {
             const uint64_t m = __ballot(skey == k);
             if (skey == k) my_rank = lane_rank(m);
-            if (lane == k) s_kcnt[k * (MCPT_BLOCK / 64) + wv] = (uint32_t)__popcll(m);
+            if (lane == k) s_kcnt[k * (WF_SHADE_BLOCK / 64) + wv] = (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < K_COUNT * (MCPT_BLOCK / 64); i++) { const uint32_t c = s_kcnt[i]; s_kcnt[i] = run; run += c; } }
+        if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < K_COUNT * (WF_SHADE_BLOCK / 64); i++) { const uint32_t c = s_kcnt[i]; s_kcnt[i] = run; run += c; } }
         __syncthreads();
-        s_perm[s_kcnt[skey * (MCPT_BLOCK / 64) + wv] + my_rank] = tid | (key << 16);
+        s_perm[s_kcnt[skey * (WF_SHADE_BLOCK / 64) + wv] + my_rank] = tid | (key << 16);
         __syncthreads();
     }
 #ifdef MCPT_SHADE_PERM_TEST     // diagnostic: a class-blind interleave -- every wave touches every line of the window, no sorting benefit
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
         if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(m);
         __syncthreads();
         if (tid == 0) {
-            uint32_t tot = 0; for (uint32_t k = 0; k < MCPT_BLOCK / 64; k++) tot += s_wave_cnt[k];
+            uint32_t tot = 0; for (uint32_t k = 0; k < WF_SHADE_BLOCK / 64; k++) tot += s_wave_cnt[k];
             uint32_t b0 = 0xffffffffu, sel = 0;
             if (tot) {
                 for (uint32_t probe = 0; probe < 4; probe++) {
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
                 uint32_t before = 0;
                 for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
                 const uint32_t l = s_base + before + lane_rank(m);
-                const uint32_t item = ((l / MCPT_BLOCK) * WF_ITEM_SHARDS + s_sel) * MCPT_BLOCK + (l % MCPT_BLOCK);
+                const uint32_t item = ((l / WF_SHADE_BLOCK) * WF_ITEM_SHARDS + s_sel) * WF_SHADE_BLOCK + (l % WF_SHADE_BLOCK);
                 if (p.probe_n) {                                            // probe: item = film entry, one sample
                     if (item < p.probe_n) { id.x = item; id.z = p.first_sample; id.w = p.first_sample + 1u; }
                 } else if (item < n_items) {
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_ker
     const uint64_t ms = __ballot(emit_shadow);
     if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(ms);
     __syncthreads();
-    if (tid == 0) { uint32_t tot = 0; for (uint32_t k = 0; k < MCPT_BLOCK / 64; k++) tot += s_wave_cnt[k]; st_s(&pool.shadow_count[blockIdx.x], tot); }
+    if (tid == 0) { uint32_t tot = 0; for (uint32_t k = 0; k < WF_SHADE_BLOCK / 64; k++) tot += s_wave_cnt[k]; st_s(&pool.shadow_count[blockIdx.x], tot); }
     if (emit_shadow) {
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     // Ray list = 2 * P / 256 chunks: chunk c < P/256 holds the extend rays of slots [256 c, 256 c + 256); chunk P/256 + b holds the
     // shadow rays shade block b queued (shadow_count[b] of them).  A wave owns one chunk at a time: the first statically (no atomic),
     // later ones from `head`.
-    const uint32_t n_ext_chunks = P / MCPT_BLOCK, n_chunks = 2 * n_ext_chunks;
+    const uint32_t n_ext_chunks = P / WF_SHADE_BLOCK, n_chunks = 2 * n_ext_chunks;
     uint32_t* head = &ctl->trace_head[it & 3];
     const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
     uint32_t w_next = 0, w_end = 0, q_base = 0;      // current chunk: item range [w_next, w_end); shadow chunks: queue offset q_base
@@ -497,9 +497,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
         if (shadow) cnt = wave_first(ld_s(&pool.shadow_count[b]));
         exhausted = exhausted || none;
         chunk_shadow = shadow;
-        q_base = b * MCPT_BLOCK;
-        w_next = ext ? c * MCPT_BLOCK : 0u;
-        w_end = ext ? c * MCPT_BLOCK + MCPT_BLOCK : cnt;
+        q_base = b * WF_SHADE_BLOCK;
+        w_next = ext ? c * WF_SHADE_BLOCK : 0u;
+        w_end = ext ? c * WF_SHADE_BLOCK + WF_SHADE_BLOCK : cnt;
     };
     // chunks are reserved WF_CHUNK_BATCH at a time: one atomic on `head` per ~1-2 k rays per wave
     uint32_t c_next = (blockIdx.x * (WF_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) * WF_CHUNK_BATCH, c_end = c_next + WF_CHUNK_BATCH;
@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 // ====================================================================================================== launchers
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
                            float4* accum, DevCounters* cnt, hipStream_t stream) {
-    const dim3 grid(pool.P / MCPT_BLOCK), block(MCPT_BLOCK);
+    const dim3 grid(pool.P / WF_SHADE_BLOCK), block(WF_SHADE_BLOCK);
     if (p.flags & MCPT_FLAG_COUNT_TRAVERSAL) hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, stream, sc, p, pool, ctl, iteration, n_items, accum, cnt);
     else hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, stream, sc, p, pool, ctl, iteration, n_items, accum, cnt);
     return hipGetLastError();
