@@ -10,7 +10,9 @@ says otherwise -- they are parity / roofline cases, the headline number is c2.
 One "step" = one complete render job of the scene already resident in HBM: clear the film, one mcpt_render call (a stream of
 [shade, trace] kernel launches over the HBM path pool), and -- with N > 1 ranks -- one RCCL all-reduce of the fp32
 films inside the timed region, the path's only exchange step.  Rank r of step s renders samples [(s*N + r)*spp, ...): work per
-GPU is fixed => "scaling": "weak".
+GPU is fixed => "scaling": "weak".  `--shard tiles` is BASELINE.json's "pixel-tile shard" instead: rank r renders ALL samples of the
+8x8 pixel tiles t with t % N == r (mcpt_render_tiles), the films are disjoint and the same all-reduce assembles the image; the job
+is then fixed => "scaling": "strong".
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts N worker processes itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/
 MASTER_* set, 127.0.0.1 rendezvous) BEFORE anything touches the GPU or imports torch; under torch.distributed.run the
@@ -129,6 +131,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json configuration (default c2 = the headline)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per step")
+    ap.add_argument("--shard", choices=["samples", "tiles"], default="samples",
+                    help="N > 1: each rank renders its own sample range of every pixel (default; weak scaling) or its interleaved share of the "
+                         "8x8 pixel tiles for all samples (BASELINE.json's 'pixel-tile shard'; strong scaling: the job is fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--dry", action="store_true", help="launcher / collective rehearsal without a GPU: no rendering, films are synthetic")
@@ -207,7 +212,10 @@ def main():
     def step(s):                            # one step = one complete render job: clear the film, render this rank's sample range, sum the films
         with torch.cuda.stream(side):
             accum.zero_()
-            r.render(spp, seed=20251004, first_sample=mg.first_sample(s, rank, world, spp))
+            if args.shard == "tiles":
+                r.render_tiles(spp, 20251004, s * spp, *mg.tile_shard(rank, world))
+            else:
+                r.render(spp, seed=20251004, first_sample=mg.first_sample(s, rank, world, spp))
             mg.all_reduce_film(accum)       # RCCL sum over xGMI, ordered after the render on `side` (no-op for one rank)
 
     def fence():
@@ -226,7 +234,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     c = r.counters()
-    film_ok = bool((accum.view(-1, 4)[:, 3] == float(spp * n_ranks)).all().item())   # every pixel got every rank's samples of the last step
+    want_count = float(spp if args.shard == "tiles" else spp * n_ranks)
+    film_ok = bool((accum.view(-1, 4)[:, 3] == want_count).all().item())   # every pixel got all the samples of the last step, from every rank
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays = torch.tensor([float(c.rays)], dtype=torch.float64, device=dev)
     paths = torch.tensor([float(c.paths)], dtype=torch.float64, device=dev)
@@ -285,12 +294,13 @@ def main():
         out = {
             "metric": "Mray/s (primary+secondary), cornell-box 1024spp", "value": round(total_rays / dt / 1e6, 2), "unit": "Mray/s",
             "n_gpus": n_ranks, "rccl_ranks": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if (args.shard == "tiles" and n_ranks > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"name": args.config,
                        "workload": "%s, %d spp/step/GPU%s, MIS integrator, reference-faithful shadow rays" % (
                            cfg["label"], spp, "" if spp == cfg["spp"] else " (of the config's %d)" % cfg["spp"]),
                        "n_tris": int(info.n_tris), "scene_device_bytes": int(info.device_bytes),
-                       "parallelism": "sample-range shard x%d + RCCL all-reduce of the %dx%dx4 fp32 film" % (n_ranks, W, H)},
+                       "parallelism": "%s shard x%d + RCCL all-reduce of the %dx%dx4 fp32 film" % (
+                           "interleaved 8x8 pixel-tile" if args.shard == "tiles" else "sample-range", n_ranks, W, H)},
             "mpath_per_s": round(total_paths / dt / 1e6, 2), "rays_per_path": round(total_rays / max(1.0, total_paths), 3),
             "ray_definition": "value counts rays actually traversed (shadow rays rejected by the reference's light self-occlusion are decided "
                               "without traversal and NOT counted: %.3f rays/path); the CPU reference traverses those too (%.3f rays/path), "

@@ -145,6 +145,11 @@ uint32_t    mcpt_abi_version(void);
  * only on (seed, pixel, sample index), so any split of a sample range over calls, GPUs or ranks yields the
  * same image up to fp32 summation order.  Asynchronous on the context's stream. */
 mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t first_sample);
+/* The same for the pixels of ONE interleaved share of the image only: 8x8-pixel tiles are numbered row-major and this call renders the
+ * tiles t with t % tile_mod == tile_rem (every other pixel of the film is left untouched).  GPU g of G renders (G, g): the
+ * "pixel-tile shard" of BASELINE.json's bathroom2 configuration -- the films of the G shares are disjoint and their sum (the same RCCL
+ * all-reduce as for sample sharding) is the full image.  (1, 0) = mcpt_render. */
+mcpt_status mcpt_render_tiles(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t first_sample, uint32_t tile_mod, uint32_t tile_rem);
 mcpt_status mcpt_sync(mcpt_ctx* ctx);
 
 /* Film = Scene::m_Pixels (Scene.h:7-12,25): width*height records {r_sum, g_sum, b_sum, spp}, index y*width+x,

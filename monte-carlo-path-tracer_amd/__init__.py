@@ -158,6 +158,7 @@ def load_library() -> C.CDLL:
         "mcpt_check_scene": [P(SceneDesc), P(SceneInfo)],
         "mcpt_get_scene_info": [vp, P(SceneInfo)],
         "mcpt_render": [vp, C.c_uint32, C.c_uint64, C.c_uint32],
+        "mcpt_render_tiles": [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32],
         "mcpt_sync": [vp],
         "mcpt_read_accum": [vp, vp],
         "mcpt_write_accum": [vp, vp],
@@ -192,7 +193,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "mcpt_create", "mcpt_destroy", "mcpt_check_scene", "mcpt_get_scene_info", "mcpt_last_error", "mcpt_abi_version",
-    "mcpt_render", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap",
+    "mcpt_render", "mcpt_render_tiles", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap",
     "mcpt_get_counters", "mcpt_reset_counters", "mcpt_bind_accum", "mcpt_accum_device_ptr", "mcpt_set_stream",
     "mcpt_set_null_stream", "mcpt_probe_trace", "mcpt_probe_trace4", "mcpt_probe_cast_ray", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
     "mcpt_probe_paths", "mcpt_probe_rng", "mcpt_probe_texture",
@@ -248,6 +249,10 @@ class Renderer:
     # ---- hot path
     def render(self, spp: int, seed: int = 0, first_sample: int = 0):
         self._check(self.lib.mcpt_render(self.ctx, spp, seed, first_sample))
+
+    def render_tiles(self, spp: int, seed: int, first_sample: int, tile_mod: int, tile_rem: int):
+        """One interleaved share of the image: the 8x8 tiles t with t % tile_mod == tile_rem."""
+        self._check(self.lib.mcpt_render_tiles(self.ctx, spp, seed, first_sample, tile_mod, tile_rem))
 
     def sync(self):
         self._check(self.lib.mcpt_sync(self.ctx))

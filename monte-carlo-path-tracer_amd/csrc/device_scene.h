@@ -95,6 +95,8 @@ struct RenderParams {
     uint32_t samples_per_item;     // samples one lane traces back-to-back
     uint32_t chunks;               // ceil(spp / samples_per_item)
     uint32_t tiles_x, tiles_y;     // 8x8 pixel tiles
+    uint32_t tile_mod, tile_rem;   // this call owns the tiles t with t % tile_mod == tile_rem (1, 0 = all: the default; interleaved tile
+    uint32_t n_owned;              //   sharding across GPUs uses world, rank) -- n_owned of them: tile k of the call = tile_rem + k * tile_mod
     uint32_t max_depth;            // 0 = unbounded
     uint32_t flags;                // MCPT_FLAG_*
     uint32_t integrator;

@@ -62,8 +62,8 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_mis_kernel(
     const uint32_t lb = PROBE ? blockIdx.x : xcd_band_block(blockIdx.x, gridDim.x);
     const uint32_t wave = lb * (MCPT_BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n_tiles = p.tiles_x * p.tiles_y;
-    const uint32_t chunk = PROBE ? 0u : wave / n_tiles, tile = wave - chunk * n_tiles;
+    const uint32_t n_tiles = p.n_owned;
+    const uint32_t chunk = PROBE ? 0u : wave / n_tiles, tile = p.tile_rem + (wave - chunk * n_tiles) * p.tile_mod;
     const int px = (int)((tile % p.tiles_x) * 8 + (lane & 7)), py = (int)((tile / p.tiles_x) * 8 + (lane >> 3));
     const bool valid = PROBE ? (wave * 64 + lane < probe_n) : (chunk < p.chunks && px < sc.cam.width && py < sc.cam.height);
     const uint32_t pixel = PROBE ? (wave * 64 + lane) : (uint32_t)(py * sc.cam.width + px);
@@ -204,8 +204,8 @@ __global__ void __launch_bounds__(MCPT_BLOCK, MCPT_MIN_WAVES) render_recursive_k
     const uint32_t lb = xcd_band_block(blockIdx.x, gridDim.x);
     const uint32_t wave = lb * (MCPT_BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n_tiles = p.tiles_x * p.tiles_y;
-    const uint32_t chunk = wave / n_tiles, tile = wave - chunk * n_tiles;
+    const uint32_t n_tiles = p.n_owned;
+    const uint32_t chunk = wave / n_tiles, tile = p.tile_rem + (wave - chunk * n_tiles) * p.tile_mod;
     const int px = (int)((tile % p.tiles_x) * 8 + (lane & 7)), py = (int)((tile / p.tiles_x) * 8 + (lane >> 3));
     const bool valid = chunk < p.chunks && px < sc.cam.width && py < sc.cam.height;
     const uint32_t pixel = (uint32_t)(py * sc.cam.width + px);
@@ -361,7 +361,7 @@ __global__ void probe_rng_kernel(uint32_t n, const uint32_t* key3, uint32_t seed
 
 // ---------------------------------------------------------------------------------------------- launchers
 hipError_t launch_render(const DevScene& sc, const RenderParams& p, float4* accum, DevCounters* cnt, hipStream_t stream) {
-    const uint64_t waves = (uint64_t)p.tiles_x * p.tiles_y * p.chunks;
+    const uint64_t waves = (uint64_t)p.n_owned * p.chunks;
     const uint32_t blocks = (uint32_t)((waves + (MCPT_BLOCK / 64) - 1) / (MCPT_BLOCK / 64));
     if (blocks == 0) return hipSuccess;
     const bool count = (p.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;

@@ -338,7 +338,7 @@ static mcpt_status resolve_timing(mcpt_ctx* c) {
 static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* accum) {
     // One mcpt_render call = per sub-pipeline a loop of [shade, trace] launches over its slot pool until its work items are done.
     // The sample range is split contiguously over the sub-pipelines; their streams fork from and join the context's stream.
-    const uint64_t tiles = uint64_t(p0.tiles_x) * p0.tiles_y;
+    const uint64_t tiles = p0.n_owned;
     const uint32_t n_lanes = p0.probe_n ? 1u : uint32_t(ctx->lanes.size());    // a probe (mcpt_probe_paths) runs on one sub-pipeline
     const bool count = (p0.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
     const uint32_t CHECK = 4, RING = 8;
@@ -438,14 +438,21 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
     return MCPT_OK;
 }
 
-mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t first_sample) {
+mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t first_sample) { return mcpt_render_tiles(ctx, spp, seed, first_sample, 1u, 0u); }
+
+mcpt_status mcpt_render_tiles(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t first_sample, uint32_t tile_mod, uint32_t tile_rem) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (tile_mod == 0 || tile_rem >= tile_mod) return fail(MCPT_ERR_INVALID_ARG, "mcpt_render_tiles: need tile_rem < tile_mod");
     if (spp == 0) return MCPT_OK;
     st = resolve_timing(ctx); if (st != MCPT_OK) return st;
     RenderParams p; std::memset(&p, 0, sizeof p);
     p.spp = spp; p.first_sample = first_sample;
     p.tiles_x = uint32_t((ctx->width + 7) / 8); p.tiles_y = uint32_t((ctx->height + 7) / 8);
-    const uint64_t tiles = uint64_t(p.tiles_x) * p.tiles_y;
+    p.tile_mod = tile_mod; p.tile_rem = tile_rem;
+    {   const uint64_t all = uint64_t(p.tiles_x) * p.tiles_y;
+        p.n_owned = all > tile_rem ? uint32_t((all - tile_rem + tile_mod - 1) / tile_mod) : 0u; }
+    if (p.n_owned == 0) return MCPT_OK;                                   // more shards than tiles: nothing for this one
+    const uint64_t tiles = p.n_owned;
     uint32_t spi = ctx->opts.samples_per_item;
     if (ctx->opts.flags & MCPT_FLAG_DETERMINISTIC) spi = spp;               // one lane owns a pixel for the whole call
     else if (spi == 0) {
@@ -454,7 +461,7 @@ mcpt_status mcpt_render(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32_t fir
             // atomics at once, or (b) the item count would overflow the cursor range.  Short items keep the end-of-render drain
             // short (a slot works its item off sample after sample: 8-sample items cost 2.7 % at 1024 spp on the bench workload)
             // and cost nothing any more now that items come from sharded cursors with one atomic per block.
-            const uint64_t slots = uint64_t(ctx->lanes[0].pool.P) * ctx->lanes.size(), pixels = uint64_t(ctx->width) * ctx->height;
+            const uint64_t slots = uint64_t(ctx->lanes[0].pool.P) * ctx->lanes.size(), pixels = tiles * 64;   // the pixels this call owns
             spi = 1;
             while (spi < 64 && slots > pixels * 32ull * spi) spi <<= 1;
             while (tiles * ((spp + spi - 1) / spi) > 0x3ffffffull && spi < spp) spi <<= 1;
@@ -705,7 +712,7 @@ mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, co
     Scratch s; double *d_o, *d_d; float* d_out; DevCounters* d_cnt;
     HIP_TRY(s.in(origin, 3 * size_t(n), &d_o)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.out(3 * size_t(n), &d_out)); HIP_TRY(s.out(1, &d_cnt));
     RenderParams p; std::memset(&p, 0, sizeof p);
-    p.spp = 1; p.first_sample = 0; p.samples_per_item = 1; p.chunks = 1; p.tiles_x = 0x7fffffffu; p.tiles_y = 1;
+    p.spp = 1; p.first_sample = 0; p.samples_per_item = 1; p.chunks = 1; p.tiles_x = 0x7fffffffu; p.tiles_y = 1; p.tile_mod = 1; p.tile_rem = 0; p.n_owned = 0x7fffffffu;
     p.max_depth = ctx->opts.max_depth; p.flags = ctx->opts.flags & ~MCPT_FLAG_COUNT_TRAVERSAL; p.integrator = MCPT_INTEGRATOR_MIS;
     p.seed_lo = uint32_t(seed); p.seed_hi = uint32_t(seed >> 32);
     if (ctx->use_wavefront) {

@@ -346,9 +346,9 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
                 if (p.probe_n) {                                            // probe: item = film entry, one sample
                     if (item < p.probe_n) { id.x = item; id.z = p.first_sample; id.w = p.first_sample + 1u; }
                 } else if (item < n_items) {
-                    const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+                    const uint32_t n_tiles = p.n_owned;
                     const uint32_t iw = item >> 6, il = item & 63u;
-                    const uint32_t chunk = iw / n_tiles, tile = iw - chunk * n_tiles;
+                    const uint32_t chunk = iw / n_tiles, tile = p.tile_rem + (iw - chunk * n_tiles) * p.tile_mod;
                     const uint32_t px = (tile % p.tiles_x) * 8 + (il & 7), py = (tile / p.tiles_x) * 8 + (il >> 3);
                     if (px < (uint32_t)sc.cam.width && py < (uint32_t)sc.cam.height) {
                         id.x = py * (uint32_t)sc.cam.width + px;

@@ -19,3 +19,9 @@ def all_reduce_film(accum, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
     return accum
+
+
+def tile_shard(rank: int, world: int):
+    """(tile_mod, tile_rem) of the interleaved pixel-tile partition (BASELINE.json configs[3] wording): rank r renders every 8x8 tile t
+    with t % world == r, for ALL samples; the per-rank films are disjoint and the same all-reduce sums them into the full image."""
+    return world, rank

@@ -43,3 +43,16 @@ def test_under_an_external_launcher_no_second_spawn():
     assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
     lines = [l for o in outs for l in o[0].splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_tile_shard_helper_partitions_tiles(pkg):
+    from importlib import import_module
+    mg = import_module("mcpt_amd.multigpu")
+    for world in (1, 2, 8):
+        seen = set()
+        for rank in range(world):
+            mod, rem = mg.tile_shard(rank, world)
+            mine = {t for t in range(1000) if t % mod == rem}
+            assert not (seen & mine)
+            seen |= mine
+        assert seen == set(range(1000))

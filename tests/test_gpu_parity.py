@@ -731,6 +731,29 @@ def test_depth_one_and_tiny_images(pkg, orc, res):
     assert c.paths == res[0] * res[1] * 32 and c.rays_continuation <= c.paths     # at most one continuation ray per path
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_interleaved_tile_shares_are_disjoint_and_sum_to_the_image(pkg, world):
+    """BASELINE.json configs[3] says "pixel-tile shard": mcpt_render_tiles(world, rank) renders the 8x8 tiles t with t % world == rank.
+    The shares rendered one after another on this GPU (what `world` GPUs would do at once) must not overlap, must each hold all the
+    samples of their pixels, and must sum -- the RCCL all-reduce of the multi-GPU run -- to the film of one mcpt_render call."""
+    scene = pkg.scenes.cornell_box_small(83, 45)                          # 11 x 6 tiles, ragged right / top edges
+    spp = 6
+    r = pkg.Renderer(scene, max_depth=5, flags=pkg.FLAG_DETERMINISTIC)
+    r.render(spp, seed=4); whole = r.read_accum()
+    total = np.zeros_like(whole); owners = np.zeros(whole.shape[:2], np.int32)
+    for rank in range(world):
+        r.clear(); r.render_tiles(spp, 4, 0, world, rank); part = r.read_accum()
+        assert set(np.unique(part[..., 3])) <= {0.0, float(spp)}
+        owners += (part[..., 3] > 0)
+        total += part
+    r.close()
+    assert np.all(owners == 1)                                            # every pixel belongs to exactly one share
+    tiles = (np.arange(45)[:, None] // 8) * 11 + (np.arange(83)[None, :] // 8)
+    r2 = pkg.Renderer(scene, max_depth=5, flags=pkg.FLAG_DETERMINISTIC); r2.render_tiles(spp, 4, 0, world, 1); one = r2.read_accum(); r2.close()
+    assert np.array_equal(one[..., 3] > 0, tiles % world == 1)            # ... the interleaved one
+    assert np.array_equal(total, whole)                                   # same samples, same per-pixel order (deterministic mode)
+
+
 def test_frame_by_frame_equals_one_call(pkg):
     """The reference's usage pattern: `frames` calls of one sample each == one call of `frames` samples."""
     scene = pkg.scenes.cornell_box_small(32, 32)
