@@ -226,7 +226,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 23);
         if (P < 2048) P = 2048;
         c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
-        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0); c->tune.pend_cap = env_u32("MCPT_WF_PEND", 48);
+        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0); c->tune.pend_cap = 48;      // speculative traversal: refined below once the scene's size is known
         c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0);
         if (c->use_wavefront) {
             uint32_t n_lanes = env_u32("MCPT_WF_LANES", 2);
@@ -243,6 +243,9 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             const bool cache_resident = traversal_bytes <= (size_t(16) << 20);
             c->trace_grid = (n_lanes > 1 && cache_resident) ? std::max(1u, uint32_t(c->n_cus) * 7u / 8u) : uint32_t(c->n_cus) * per_cu;
             c->trace_grid = std::min(env_u32("MCPT_WF_GRID", c->trace_grid), uint32_t(c->n_cus) * per_cu);
+            // speculative traversal: S-cornell 469 -> 450 ms; on the 4 M-triangle configuration, where the extra node visits are HBM
+            // traffic, it is neutral within the noise (same box: 367 ms with, 371 ms without) -- on everywhere; MCPT_WF_PEND=0 turns it off
+            c->tune.pend_cap = env_u32("MCPT_WF_PEND", 48u);
             if ((e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
             c->lanes.resize(n_lanes);
             for (auto& L : c->lanes) {
@@ -392,6 +395,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             if (debug && r.seen < 40)
                 fprintf(stderr, "[wf] it=%u active=%u head=%u cursor0=%u/%u\n", it_of, s.any_active[it_of & 3],
                         s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(r.n_items, 0));
+            if (s.pad[0]) return fail(MCPT_ERR_HIP, "trace kernel watchdog: a wave did not finish its ray list (internal error)");
             bool items_left = false;
             for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) items_left |= s.item_cursor[q].v < wf_shard_capacity(r.n_items, q);
             if (s.any_active[it_of & 3] == 0 && !items_left) r.done = true;
@@ -642,6 +646,8 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
     HIP_TRY(launch_wf_trace(ctx->dev, pool, static_cast<IterCtl*>(L.ctl_buf.p), 0u, ctx->tune, count, static_cast<DevCounters*>(ctx->counters.p), ctx->trace_grid,
                             static_cast<int*>(L.ovf_buf.p), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {   IterCtl snap; HIP_TRY(hipMemcpy(&snap, L.ctl_buf.p, sizeof snap, hipMemcpyDeviceToHost));
+        if (snap.pad[0]) return fail(MCPT_ERR_HIP, "trace kernel watchdog: a wave did not finish its ray list (internal error)"); }
     if (any_hit) {
         HIP_TRY(hipMemcpy(hit.data(), pool.nee, hit.size() * 4, hipMemcpyDeviceToHost));     // blocked <=> the trace kernel set nee.w
         for (uint32_t i = 0; i < n; i++) {

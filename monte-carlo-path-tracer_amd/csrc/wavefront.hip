@@ -516,7 +516,11 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     int pend = 0;
 #define WF_PEND pend
 #define WF_POP_NODE() { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = OVF(sp - WF_LDS_STACK); }
-#define WF_PARK_LEAF() if (pend == 0 && node < 0 && node != MCPT_NODE_SENTINEL) { pend = node; WF_POP_NODE() }
+    // tune.pend_cap == 0 (MCPT_WF_PEND=0, a developer knob) switches the speculation off: the lane parks its leaf all the same but
+    // waits for it (node = WF_NODE_WAIT).
+#define WF_NODE_WAIT ((int)0x80000001)
+    const bool speculate = tune.pend_cap != 0u;
+#define WF_PARK_LEAF() if (pend == 0 && node < 0 && node != MCPT_NODE_SENTINEL && node != WF_NODE_WAIT) { pend = node; if (speculate) WF_POP_NODE() else node = WF_NODE_WAIT; }
 #else
 #define WF_PEND 0
 #define WF_PARK_LEAF()
@@ -532,7 +536,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #endif
     const bool greedy = tune.policy == 1;
 
+    uint32_t watchdog = 0;                            // scheduler rounds of this wave: a logic error must end the launch, not hang the GPU
     for (;;) {
+        if (++watchdog > (1u << 24)) { if (lane == 0) ctl->pad[0] = 1u; break; }   // (~10^3 cycles per round: seconds; a launch needs ~10^3 rounds)
         const bool at_inner = have && node >= 0;
 #ifndef WF_NO_POSTPONE
         const bool at_leaf = have && pend != 0;                                    // has a parked leaf (may still be descending)
@@ -609,7 +615,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
         }
 
 #ifndef WF_NO_POSTPONE
-        if (n_leaf >= (int)tune.leaf_at || n_inner == 0 || n_pend >= (int)tune.pend_cap) {
+        if (n_leaf >= (int)tune.leaf_at || n_inner == 0 || (speculate && n_pend >= (int)tune.pend_cap)) {
 #else
         if ((greedy ? n_leaf >= n_inner : n_leaf >= (int)tune.leaf_at) || n_inner == 0) {
 #endif
@@ -664,7 +670,10 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #ifndef WF_NO_POSTPONE
                 pend = 0;
                 if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
-                else WF_PARK_LEAF()                                      // the lane was waiting AT another leaf: park that one now
+                else {
+                    if (node == WF_NODE_WAIT) WF_POP_NODE()              // (no speculation: the lane resumes where it stopped)
+                    WF_PARK_LEAF()                                       // the lane was waiting AT another leaf: park that one now
+                }
 #else
                 if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
                 else { sp = sp1; node = popped; }
@@ -768,6 +777,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #undef WF_PARK_LEAF
 #ifndef WF_NO_POSTPONE
 #undef WF_POP_NODE
+#undef WF_NODE_WAIT
 #endif
 // ====================================================================================================== launchers
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
