@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t wave_first(uint32_t v) { return __builtin_am
 // record (tri_isect[].v0.w) into the triangle index it writes back -- no extra fetch.  All slot traffic of the permuted lanes stays
 // inside the block's own 256-slot window of each pool array (the same cache lines the block would read in slot order).
 #ifndef MCPT_SHADE_MIN_WAVES
-#define MCPT_SHADE_MIN_WAVES 1
+#define MCPT_SHADE_MIN_WAVES 5      // => 96 VGPRs without scratch (100 unconstrained): five waves per SIMD where no trace block shares the CU
 #endif
 #define K_END 0u
 #define K_EMIT 1u
