@@ -688,6 +688,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
         // plane after one v_cvt_f32_ubyteN.  Hit children are ordered by entry distance (5-comparator network); the nearest is
         // visited next, the others go on the stack far-to-near.  Top levels come from LDS, the rest from memory.
         int keep = (int)tune.inner_keep;
+        const bool order_matters = __ballot(have && !any) != 0;
         do {
 #ifdef WF_SCHED_STATS
             x_inner++; if (have && node >= 0) n_box++;
@@ -724,10 +725,15 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #endif
                 int cd0 = __float_as_int(D.x), cd1 = __float_as_int(D.y), cd2 = __float_as_int(D.z), cd3 = __float_as_int(D.w);
 #define WF_CSWAP(KA, CA, KB, CB) { const bool sw = KB < KA; const float tk = sw ? KB : KA; KB = sw ? KA : KB; KA = tk; const int tc = sw ? CB : CA; CB = sw ? CA : CB; CA = tc; }
-                WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2) WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
+                // any-hit rays (Render.cpp:125: is the light visible at all) do not care in which order the children are visited, and the ray
+                // list hands a wave long runs of one kind (all extend chunks come before all shadow chunks): while no lane of the wave
+                // carries a closest-hit ray the 5-comparator network is skipped (a wave-uniform branch)
+                if (order_matters) {
+                    WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2) WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
+                }
 #undef WF_CSWAP
                 const float inf = __builtin_inff();
-                const int h1 = key1 < inf, h2 = key2 < inf, h3 = key3 < inf;      // sorted: hits are a prefix
+                const int h1 = key1 < inf, h2 = key2 < inf, h3 = key3 < inf;      // (sorted: hits are a prefix; unsorted: any pattern -- the pushes below handle both)
                 if (sp + 3 <= WF_LDS_STACK) {
                     // common case, branch-free: store all three candidates, advance the stack pointer only past real hits (a slot
                     // written without the bump is simply overwritten later); the pop reads the slot below the new top
