@@ -558,8 +558,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
             x_refill++; l_refill += (uint32_t)n_idle;
 #endif
             if (have && node == MCPT_NODE_SENTINEL && WF_PEND == 0) {    // finished: write the result back
-                if (slot >= P) { if (lane == (uint32_t)__builtin_ctzll(__ballot(slot >= P))) ctl->pad[0] = 2u; }   // cannot happen; never write out of bounds
-                else if (any) {                                               // Render.cpp:125-130: the verdict.  The next shade call adds the
+                if (any) {                                               // Render.cpp:125-130: the verdict.  The next shade call adds the
                     if (blocked) st_s(reinterpret_cast<uint32_t*>(&pool.nee[slot]) + 3, 1u);   // ... NEE term it parked in pool.nee unless .w says "blocked"
                 } else {
                     st_s(&pool.hit[slot], make_float4(__int_as_float(htri), hu, hv, tmax));   // closest hit: tmax IS its distance
