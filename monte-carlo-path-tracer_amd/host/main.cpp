@@ -17,7 +17,7 @@
 #include "Render.h"
 
 static void usage() {
-    std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
+    std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--shard samples|tiles] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
                  "                          [--deterministic] [--ref-index-order] [--gpu-bvh] [--check] [--dump-model file]\n"
                  "       mcpt_cli --decode-image texture.(png|jpg|ppm) out.ppm\n";
 }
@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     std::string filename = argv[1], out, dump_model;
-    uint32_t spp = 64, batch = 0, depth = 0, gpus = 1; uint64_t seed = 20251004; uint32_t flags = 0, integrator = 0; bool ref_order = false, check_only = false;
+    uint32_t spp = 64, batch = 0, depth = 0, gpus = 1; uint64_t seed = 20251004; uint32_t flags = 0, integrator = 0; bool ref_order = false, check_only = false, shard_tiles = false;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i]; auto next = [&]() { return i + 1 < argc ? argv[++i] : (char*)"0"; };
         if (a == "--spp") spp = uint32_t(std::atoi(next())); else if (a == "--batch") batch = uint32_t(std::atoi(next()));
@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
         else if (a == "--gpu-bvh") flags |= MCPT_FLAG_GPU_BVH_BUILD;
         else if (a == "--check") check_only = true;
         else if (a == "--dump-model") dump_model = next();
+        else if (a == "--shard") shard_tiles = std::string(next()) == "tiles";
         else { usage(); return 2; }
     }
     Model model(filename, ref_order);
@@ -118,7 +119,10 @@ int main(int argc, char** argv) {
             const uint32_t lo = frame + uint32_t(uint64_t(n) * g / gpus), hi = frame + uint32_t(uint64_t(n) * (g + 1) / gpus);
             mcpt_ctx* c = renders[g]->handle();
             if (mcpt_clear_accum(c) != MCPT_OK) return fail_with(std::string("mcpt_clear_accum: ") + mcpt_last_error());
-            if (hi > lo && mcpt_render(c, hi - lo, seed, lo) != MCPT_OK) return fail_with(std::string("mcpt_render: ") + mcpt_last_error());
+            // --shard tiles: device g renders ALL n samples of its interleaved share of the 8x8 tiles (BASELINE.json's "pixel-tile shard");
+            // default: its contiguous share of the sample range for every pixel.  Either way the films add up to the frame.
+            const mcpt_status rs = shard_tiles ? mcpt_render_tiles(c, n, seed, frame, gpus, g) : (hi > lo ? mcpt_render(c, hi - lo, seed, lo) : MCPT_OK);
+            if (rs != MCPT_OK) return fail_with(std::string("mcpt_render: ") + mcpt_last_error());
             if (mcpt_sync(c) != MCPT_OK) return fail_with(std::string("mcpt_sync: ") + mcpt_last_error());
         });
         for (auto& t : th) t.join();
