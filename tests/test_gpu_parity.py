@@ -759,6 +759,20 @@ def test_interleaved_tile_shares_are_disjoint_and_sum_to_the_image(pkg, world):
     assert np.array_equal(total, whole)                                   # same samples, same per-pixel order (deterministic mode)
 
 
+def test_tile_shares_through_the_megakernel_paths(pkg):
+    """The same partition through the cross-check megakernel (MCPT_PIPELINE=mega) and the recursive integrator, which map work items to
+    tiles in kernels.hip rather than in the wavefront shade kernel."""
+    scene = pkg.scenes.cornell_box_small(50, 30)
+    for kw, pipe in (({"integrator": pkg.INTEGRATOR_RECURSIVE_NEE}, "wave"), ({}, "mega")):
+        r = _renderer(pkg, scene, pipe, max_depth=4, flags=pkg.FLAG_DETERMINISTIC, **kw)
+        r.render(5, seed=8); whole = r.read_accum()
+        total = np.zeros_like(whole)
+        for rank in range(3):
+            r.clear(); r.render_tiles(5, 8, 0, 3, rank); total += r.read_accum()
+        r.close()
+        assert np.array_equal(total, whole), (kw, pipe)
+
+
 def test_frame_by_frame_equals_one_call(pkg):
     """The reference's usage pattern: `frames` calls of one sample each == one call of `frames` samples."""
     scene = pkg.scenes.cornell_box_small(32, 32)
