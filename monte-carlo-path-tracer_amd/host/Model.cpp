@@ -12,13 +12,27 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include <zlib.h>
 
 namespace {
+// Text after the first n characters; empty when the line is shorter (a bare "vn" must not throw).
+std::string rest(const std::string& line, size_t n) { return line.size() > n ? line.substr(n) : std::string(); }
 std::string dir_of(const std::string& p) { size_t k = p.find_last_of("/\\"); return k == std::string::npos ? std::string(".") : p.substr(0, k); }
+// Whole file as bytes; empty for anything that is not a readable regular file (reading a directory through a
+// streambuf iterator throws in libstdc++, e.g. "map_Kd" with no name resolves to the scene directory).
+template <class Bytes> Bytes read_file(const std::string& filename) {
+    Bytes out;
+    std::error_code ec;
+    if (!std::filesystem::is_regular_file(filename, ec) || ec) return out;
+    std::ifstream in(filename, std::ios::binary);
+    if (!in) return out;
+    try { out.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>()); } catch (const std::ios_base::failure&) { out.clear(); }
+    return out;
+}
 bool starts(const std::string& s, const char* t) { return s.compare(0, std::strlen(t), t) == 0; }
 
 // ---- PNG via zlib: every colour type (grey, RGB, palette, grey+alpha, RGBA), bit depths 1-16, non-interlaced; returns RGB bytes
@@ -98,8 +112,7 @@ bool load_ppm(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
 }  // namespace
 
 bool load_image_rgb8(const std::string& filename, int& w, int& h, std::vector<unsigned char>& rgb) {
-    std::ifstream in(filename, std::ios::binary);
-    std::vector<unsigned char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    const std::vector<unsigned char> bytes = read_file<std::vector<unsigned char>>(filename);
     return !bytes.empty() && (load_png(bytes, w, h, rgb) || load_jpeg(bytes, w, h, rgb) || load_ppm(bytes, w, h, rgb));
 }
 
@@ -134,18 +147,18 @@ Model::Model(const std::string& filename, bool reference_index_order) {
     while (std::getline(file, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
         if (starts(line, "mtllib")) {
-            std::istringstream ss(line.substr(6)); std::string name; ss >> name;
+            std::istringstream ss(rest(line, 6)); std::string name; ss >> name;
             if (name.size() > 3) {
                 std::string xml = name; xml.replace(xml.size() - 3, 3, "xml");
                 loadCameraFromXML(parent + "/" + xml);          // camera first: radiance is attached while materials load (model.cpp:71-72)
                 load_material(parent + "/" + name);
             }
-        } else if (starts(line, "v ")) { dvec3 v; std::istringstream ss(line.substr(2)); ss >> v.x >> v.y >> v.z; vertex.push_back(v); }
-        else if (starts(line, "vn")) { dvec3 n; std::istringstream ss(line.substr(3)); ss >> n.x >> n.y >> n.z; normal.push_back(n); }
-        else if (starts(line, "vt")) { dvec2 t; std::istringstream ss(line.substr(3)); ss >> t.x >> t.y; texture.push_back(t); }
-        else if (starts(line, "usemtl")) { std::istringstream ss(line.substr(6)); std::string name; ss >> name; auto it = material_map.find(name); cur_mtl = it == material_map.end() ? 0 : it->second; }
+        } else if (starts(line, "v ")) { dvec3 v; std::istringstream ss(rest(line, 2)); ss >> v.x >> v.y >> v.z; vertex.push_back(v); }
+        else if (starts(line, "vn")) { dvec3 n; std::istringstream ss(rest(line, 3)); ss >> n.x >> n.y >> n.z; normal.push_back(n); }
+        else if (starts(line, "vt")) { dvec2 t; std::istringstream ss(rest(line, 3)); ss >> t.x >> t.y; texture.push_back(t); }
+        else if (starts(line, "usemtl")) { std::istringstream ss(rest(line, 6)); std::string name; ss >> name; auto it = material_map.find(name); cur_mtl = it == material_map.end() ? 0 : it->second; }
         else if (starts(line, "f ")) {
-            std::istringstream ss(line.substr(2)); imat3x4 f; bool good = true;
+            std::istringstream ss(rest(line, 2)); imat3x4 f; bool good = true;
             for (int i = 0; i < 3 && good; i++) {
                 int a = 0, b = 0, c = 0; char s1 = 0, s2 = 0;
                 ss >> a >> s1 >> b >> s2 >> c;
@@ -206,9 +219,8 @@ double xml_num(const std::string& tag, const char* name) { std::string s; return
 }  // namespace
 
 void Model::loadCameraFromXML(const std::string& filename) {
-    std::ifstream in(filename);
-    if (!in.is_open()) { std::cerr << "Error: Failed to load XML file: " << filename << std::endl; return; }
-    std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    const std::string text = read_file<std::string>(filename);
+    if (text.empty()) { std::cerr << "Error: Failed to load XML file: " << filename << std::endl; return; }
     size_t p = 0; bool have_camera = false;
     while ((p = text.find('<', p)) != std::string::npos) {
         size_t e = text.find('>', p); if (e == std::string::npos) break;
