@@ -319,6 +319,8 @@ std::string validate_bvh4(const HostScene& hs) {
     return "";
 }
 
+static constexpr double kMaxCoord = 1e18;
+
 mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh, const Collapse4Fn& custom_collapse) {
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
     if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }
@@ -363,7 +365,11 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         if (c[3] < 0 || uint32_t(c[3]) >= d->n_materials) { err = "face " + std::to_string(f) + ": material out of range"; return MCPT_ERR_INVALID_ARG; }
         BTri& T = bt[f];
         for (int a = 0; a < 3; a++) {
-            const double x0 = d->vertex[3 * c[0] + a], x1 = d->vertex[3 * c[4] + a], x2 = d->vertex[3 * c[8] + a];
+            const double x0 = d->vertex[3 * size_t(c[0]) + a], x1 = d->vertex[3 * size_t(c[4]) + a], x2 = d->vertex[3 * size_t(c[8]) + a];
+            // NaN / inf coordinates have no order (the builders' partitions need one) and anything past 1e18 overflows the fp32 boxes' areas
+            if (!(std::fabs(x0) <= kMaxCoord && std::fabs(x1) <= kMaxCoord && std::fabs(x2) <= kMaxCoord)) {
+                err = "face " + std::to_string(f) + ": vertex coordinate is not finite or exceeds 1e18"; return MCPT_ERR_INVALID_ARG;
+            }
             T.lo[a] = std::min(x0, std::min(x1, x2)); T.hi[a] = std::max(x0, std::max(x1, x2));
             T.c[a] = (x0 + x1 + x2) / 3.0;
         }
@@ -437,9 +443,9 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     for (uint32_t i = i_begin; i < i_end; i++) {
         const int f = order[i];
         const int32_t* c = d->face + 12 * size_t(f);
-        const double* v0 = d->vertex + 3 * c[0]; const double* v1 = d->vertex + 3 * c[4]; const double* v2 = d->vertex + 3 * c[8];
-        const double* n0 = d->normal + 3 * c[1]; const double* n1 = d->normal + 3 * c[5]; const double* n2 = d->normal + 3 * c[9];
-        const double* t0_ = d->texcoord + 2 * c[2]; const double* t1_ = d->texcoord + 2 * c[6]; const double* t2_ = d->texcoord + 2 * c[10];
+        const double* v0 = d->vertex + 3 * size_t(c[0]); const double* v1 = d->vertex + 3 * size_t(c[4]); const double* v2 = d->vertex + 3 * size_t(c[8]);
+        const double* n0 = d->normal + 3 * size_t(c[1]); const double* n1 = d->normal + 3 * size_t(c[5]); const double* n2 = d->normal + 3 * size_t(c[9]);
+        const double* t0_ = d->texcoord + 2 * size_t(c[2]); const double* t1_ = d->texcoord + 2 * size_t(c[6]); const double* t2_ = d->texcoord + 2 * size_t(c[10]);
         const uint32_t mflags = out.mats[size_t(c[3])].flags;
         const uint32_t lobe_class = !(mflags & MAT_HAS_SPEC) ? HIT_CLASS_DIFFUSE : (mflags & MAT_MIRROR) ? HIT_CLASS_MIRROR : HIT_CLASS_PHONG;
         out.tri_isect[3 * size_t(i) + 0] = {float(v0[0]), float(v0[1]), float(v0[2]), as_float(int(lobe_class << HIT_CLASS_SHIFT))};
@@ -473,7 +479,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         L.area = 0.5f * std::sqrt((cx * cx + cy * cy) + cz * cz);                       // Triangle.cpp:24-28
         for (int a = 0; a < 3; a++) {
             L.radiance[a] = float(m.radiance[a]);
-            L.n0[a] = float(d->normal[3 * c[1] + a]); L.n1[a] = float(d->normal[3 * c[5] + a]); L.n2[a] = float(d->normal[3 * c[9] + a]);
+            L.n0[a] = float(d->normal[3 * size_t(c[1]) + a]); L.n1[a] = float(d->normal[3 * size_t(c[5]) + a]); L.n2[a] = float(d->normal[3 * size_t(c[9]) + a]);
         }
         out.lights.push_back(L);
     }

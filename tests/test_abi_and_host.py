@@ -111,6 +111,14 @@ def test_reference_undefined_behaviour_becomes_error_codes(pkg):
     assert st == 1
     st, _, _ = pkg.check_scene(pkg.scenes.SceneData(s.name, s.vertex, s.normal, s.texcoord, s.face[:0], s.materials, s.camera))
     assert st == 1
+    # coordinates without an order (NaN, inf) or past the fp32 boxes' range: the builders' partitions would never end
+    for poison in (np.nan, np.inf, -np.inf, 1e19):
+        v = s.vertex.copy(); v[int(s.face[0, 1, 0]), 2] = poison
+        st, _, msg = pkg.check_scene(pkg.scenes.SceneData(s.name, v, s.normal, s.texcoord, s.face, s.materials, s.camera))
+        assert st == 1 and "vertex coordinate" in msg, (poison, st, msg)
+    v = s.vertex.copy(); v = np.vstack([v, [[np.nan, 0, 0]]])           # an unreferenced vertex is nobody's business
+    st, _, _ = pkg.check_scene(pkg.scenes.SceneData(s.name, v, s.normal, s.texcoord, s.face, s.materials, s.camera))
+    assert st == 0
 
 
 def test_quantised_bvh4_is_conservative_on_awkward_geometry(pkg):

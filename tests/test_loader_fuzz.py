@@ -24,3 +24,14 @@ def _tool():
 def test_loader_survives_mutated_scenes(tmp_path):
     findings = _tool().run(cases=60, seed=3, workdir=str(tmp_path), verbose=False)
     assert findings == []
+
+
+@pytest.mark.skipif(shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"), reason="needs g++ and the HIP headers")
+def test_scene_builder_survives_hostile_descriptions(tmp_path):
+    """tools/fuzz_scene_build.cpp under ASan + UBSan: NaN / inf / huge coordinates, indices out of range, degenerate geometry,
+    zero-sized films and textures.  Rejected or accepted, never a crash or a hang; an accepted scene's 4-wide tree must be sound."""
+    import subprocess
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    p = subprocess.run([os.path.join(ROOT, "tools", "fuzz_scene_build.sh"), "40", "9"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "0 unsound" in p.stdout and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
