@@ -344,27 +344,42 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
     const uint64_t tiles = p0.n_owned;
     const uint32_t n_lanes = p0.probe_n ? 1u : uint32_t(ctx->lanes.size());    // a probe (mcpt_probe_paths) runs on one sub-pipeline
     const bool count = (p0.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
-    const uint32_t CHECK = 4, RING = 8;
+    constexpr uint32_t CHECK = 4, RING = 8;
     const bool debug = env_u32("MCPT_WF_DEBUG", 0) != 0;
     const uint32_t max_it = env_u32("MCPT_WF_MAXIT", 1u << 20);
     DevCounters* cnt = static_cast<DevCounters*>(ctx->counters.p);
-    struct Run { RenderParams p; PathPool pool; uint32_t n_items = 0, it = 0, issued = 0, seen = 0; size_t kev = 0; bool active = false, done = false; };
+    struct Run { RenderParams p; PathPool pool; uint32_t n_items = 0, it = 0, issued = 0, seen = 0, bound = 0, snap_it[RING] = {0}; size_t kev = 0; bool active = false, done = false; };
     std::vector<Run> runs(n_lanes);
     uint32_t n_active = 0;
+    // A call with fewer samples than sub-pipelines (the reference's one-sample-per-call loop, Render.cpp:56-69) splits its TILES over them
+    // instead of its samples -- pipeline k takes every n_lanes-th tile of this call's share -- so that the shade of one still runs
+    // beside the trace of the other.  Their pixel sets are disjoint.
+    const bool split_tiles = !p0.probe_n && p0.spp < n_lanes && tiles >= n_lanes;
     for (uint32_t k = 0; k < n_lanes; k++) {
         Run& r = runs[k];
-        const uint32_t lo = uint32_t(uint64_t(p0.spp) * k / n_lanes), hi = uint32_t(uint64_t(p0.spp) * (k + 1) / n_lanes);
-        if (hi == lo) { r.done = true; ctx->lanes[k].last_iterations = 0; continue; }
-        r.p = p0; r.p.spp = hi - lo; r.p.first_sample = p0.first_sample + lo;
+        r.p = p0;
+        uint64_t my_tiles = tiles;
+        if (split_tiles) {
+            r.p.tile_mod = p0.tile_mod * n_lanes; r.p.tile_rem = p0.tile_rem + k * p0.tile_mod;
+            my_tiles = (tiles - k + n_lanes - 1) / n_lanes; r.p.n_owned = uint32_t(my_tiles);
+        } else {
+            const uint32_t lo = uint32_t(uint64_t(p0.spp) * k / n_lanes), hi = uint32_t(uint64_t(p0.spp) * (k + 1) / n_lanes);
+            if (hi == lo) { r.done = true; ctx->lanes[k].last_iterations = 0; continue; }
+            r.p.spp = hi - lo; r.p.first_sample = p0.first_sample + lo;
+        }
         if (r.p.samples_per_item > r.p.spp) r.p.samples_per_item = r.p.spp;
         r.p.chunks = (r.p.spp + r.p.samples_per_item - 1) / r.p.samples_per_item;
-        r.n_items = p0.probe_n ? p0.probe_n : uint32_t(tiles * 64 * r.p.chunks);
+        r.n_items = p0.probe_n ? p0.probe_n : uint32_t(my_tiles * 64 * r.p.chunks);
         r.pool = ctx->lanes[k].pool;
         const uint32_t want = uint32_t(((uint64_t(r.n_items) + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK) * WF_SHADE_BLOCK);
         if (r.pool.P > want) r.pool.P = want;                              // small jobs: do not sweep idle slots
+        // Every item has a slot of its own and one sample: all paths start in iteration 0, vertex b is shaded in iteration b + 1, the
+        // depth limit ends the path by iteration max_depth + 1 and a parked NEE term (SLOT_DRAIN) costs one more.  The loop then runs
+        // exactly that many iterations before it looks at the control block for the first time -- no launches past the end of the job.
+        if (r.n_items <= r.pool.P && r.p.chunks == 1 && r.p.samples_per_item == 1 && p0.max_depth != 0 && !p0.probe_n) r.bound = p0.max_depth + 3;
         r.active = true; n_active++;
     }
-    for (Run& r : runs) if (r.active) r.p.atomic_accum = (n_active > 1 || r.p.chunks > 1) ? 1u : 0u;
+    for (Run& r : runs) if (r.active) r.p.atomic_accum = ((n_active > 1 && !split_tiles) || r.p.chunks > 1) ? 1u : 0u;
     HIP_TRY(hipEventRecord(ctx->fork_ev, ctx->stream));
     for (uint32_t k = 0; k < n_lanes; k++) {
         if (!runs[k].active) continue;
@@ -391,7 +406,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
                 if (q != hipSuccess) return hip_fail(q, "hipEventQuery");
             }
             const IterCtl& s = L.h_ctl[k];
-            const uint32_t it_of = (r.seen + 1) * CHECK - 1;               // snapshot taken after iteration it_of
+            const uint32_t it_of = r.snap_it[k];                           // snapshot taken after iteration it_of
             if (debug && r.seen < 40)
                 fprintf(stderr, "[wf] it=%u active=%u head=%u cursor0=%u/%u\n", it_of, s.any_active[it_of & 3],
                         s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(r.n_items, 0));
@@ -411,6 +426,14 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             if (!r.active || r.done) continue;
             mcpt_ctx::WfLane& L = ctx->lanes[k];
             IterCtl* ctl = static_cast<IterCtl*>(L.ctl_buf.p);
+            auto awaits_verdict = [](const Run& x) { return x.bound && x.it == x.bound && x.seen < x.issued; };
+            if (awaits_verdict(r)) {                                        // known-length job, all iterations issued: wait for its snapshot --
+                bool others = false;                                        // blocking only when no other sub-pipeline has launches left to issue
+                for (uint32_t j = 0; j < n_lanes; j++) others |= j != k && runs[j].active && !runs[j].done && !awaits_verdict(runs[j]);
+                mcpt_status ps = poll(L, r, !others); if (ps != MCPT_OK) return ps;
+                if (r.done) continue;
+                if (r.seen < r.issued) { all_done = false; continue; }
+            }
             const bool timed = ctx->time_kernels && r.it % ctx->time_kernels == 0;
             HIP_TRY(k_event(L, r, timed));
             HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_items, accum, cnt, L.stream));
@@ -418,12 +441,13 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(L.ovf_buf.p), L.stream));
             HIP_TRY(k_event(L, r, timed));
             r.it++;
-            if (r.it % CHECK == 0) {
+            if (r.bound ? (r.it >= r.bound && (r.it - r.bound) % CHECK == 0) : r.it % CHECK == 0) {
                 mcpt_status ps = poll(L, r, r.issued - r.seen >= 2); if (ps != MCPT_OK) return ps;   // at most 2 checks (8 iterations) ahead
                 if (!r.done) {
                     const uint32_t q = r.issued % RING;
                     HIP_TRY(hipMemcpyAsync(&L.h_ctl[q], ctl, sizeof(IterCtl), hipMemcpyDeviceToHost, L.stream));
                     HIP_TRY(hipEventRecord(L.chk_ev[q], L.stream));
+                    r.snap_it[q] = r.it - 1;
                     r.issued++;
                 }
             }

@@ -485,24 +485,36 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
     // Ray list = 2 * P / 256 chunks: chunk c < P/256 holds the extend rays of slots [256 c, 256 c + 256); chunk P/256 + b holds the
     // shadow rays shade block b queued (shadow_count[b] of them).  A wave owns one chunk at a time: the first statically (no atomic),
     // later ones from `head`.
-    const uint32_t n_ext_chunks = P / WF_SHADE_BLOCK, n_chunks = 2 * n_ext_chunks;
-    uint32_t* head = &ctl->trace_head[it & 3];
+    // A list with fewer chunks than waves (a small call: one sample per pixel of a small film) is handed out in quarter chunks of 64 rays,
+    // so that every wave of the grid gets rays and no lane works four of them one after the other.
+    const uint32_t n_ext_chunks = P / WF_SHADE_BLOCK;
     const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
+    const uint32_t sub_sh = 2 * n_ext_chunks < n_waves ? 2u : 0u;     // log2(parts per chunk)
+    const uint32_t n_chunks = (2 * n_ext_chunks) << sub_sh;
+    uint32_t* head = &ctl->trace_head[it & 3];
     uint32_t w_next = 0, w_end = 0, q_base = 0;      // current chunk: item range [w_next, w_end); shadow chunks: queue offset q_base
     bool chunk_shadow = false, exhausted = false;
     auto take_chunk = [&](uint32_t c) {              // (straight-line on purpose: with early returns the compiler kept w_next / w_end in scratch)
-        const bool none = c >= n_chunks, ext = c < n_ext_chunks, shadow = !none && !ext;
-        const uint32_t b = shadow ? c - n_ext_chunks : 0u;
-        uint32_t cnt = 0;
+        const uint32_t cc = c >> sub_sh, part = c & ((1u << sub_sh) - 1u), span = (uint32_t)WF_SHADE_BLOCK >> sub_sh;
+        const bool none = c >= n_chunks, ext = cc < n_ext_chunks, shadow = !none && !ext;
+        const uint32_t b = shadow ? cc - n_ext_chunks : 0u;
+        uint32_t cnt = ext ? (uint32_t)WF_SHADE_BLOCK : 0u;
         if (shadow) cnt = wave_first(ld_s(&pool.shadow_count[b]));
+        const uint32_t lo = min(part * span, cnt), hi = min(lo + span, cnt), base = ext ? cc * WF_SHADE_BLOCK : 0u;
         exhausted = exhausted || none;
         chunk_shadow = shadow;
         q_base = b * WF_SHADE_BLOCK;
-        w_next = ext ? c * WF_SHADE_BLOCK : 0u;
-        w_end = ext ? c * WF_SHADE_BLOCK + WF_SHADE_BLOCK : cnt;
+        w_next = base + lo;
+        w_end = base + hi;
     };
-    // chunks are reserved WF_CHUNK_BATCH at a time: one atomic on `head` per ~1-2 k rays per wave
-    uint32_t c_next = (blockIdx.x * (WF_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) * WF_CHUNK_BATCH, c_end = c_next + WF_CHUNK_BATCH;
+    // chunks are reserved `batch` at a time: WF_CHUNK_BATCH when the list is long (one atomic on `head` per ~1-2 k rays per wave).  A short
+    // list (a one-sample-per-pixel call: 5 000 chunks for 3 584 waves) would leave most waves -- whole CUs, with block-major wave numbers --
+    // without a first chunk: there every wave takes n_chunks / n_waves (at least one) and wave numbers interleave across the blocks.
+    const bool short_list = n_chunks < n_waves * WF_CHUNK_BATCH;
+    const uint32_t batch = short_list ? max(1u, n_chunks / n_waves) : (uint32_t)WF_CHUNK_BATCH;
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: the chunk bookkeeping below stays in SGPRs
+    const uint32_t wave_id = short_list ? wave_in_block * gridDim.x + blockIdx.x : blockIdx.x * (WF_TRACE_BLOCK / 64) + wave_in_block;
+    uint32_t c_next = wave_id * batch, c_end = c_next + batch;
     take_chunk(c_next++);
 
     bool have = false, any = false, blocked = false;
@@ -575,8 +587,8 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     if (w_next == w_end) {                               // next chunk (uniform branch)
                         if (c_next == c_end) {
                             uint32_t c = 0;
-                            if (lane == 0) c = atomicAdd(head, (uint32_t)WF_CHUNK_BATCH);
-                            c_next = wave_first(c) + n_waves * WF_CHUNK_BATCH; c_end = c_next + WF_CHUNK_BATCH;
+                            if (lane == 0) c = atomicAdd(head, batch);
+                            c_next = wave_first(c) + n_waves * batch; c_end = c_next + batch;
                         }
                         take_chunk(c_next++);
                         if (exhausted) break;

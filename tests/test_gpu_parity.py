@@ -783,6 +783,36 @@ def test_frame_by_frame_equals_one_call(pkg):
     assert np.array_equal(a[..., 3], b[..., 3]) and np.allclose(a, b, rtol=2e-5, atol=1e-5)
 
 
+def test_single_sample_calls_split_tiles_over_both_sub_pipelines(pkg, orc):
+    """A call with one sample has nothing to split by sample index: the two sub-pipelines take alternate tiles of the call's share
+    instead, and the loop runs its known number of iterations (max_depth + 3) before the first look at the control block.  Same film
+    as one multi-sample call, as the fp64 oracle, and per-rank tile shares still add up -- on a film with an odd number of tiles."""
+    scene = pkg.scenes.cornell_box_small(72, 40)                        # 9 x 5 = 45 tiles
+    spp = 6
+    flags = pkg.FLAG_CORRECT_SHADOW_T2                                  # the mode whose samples match the oracle's one for one
+    r = pkg.Renderer(scene, max_depth=5, flags=flags)
+    r.reset_counters()
+    for f in range(spp):
+        r.render(1, seed=3, first_sample=f)
+    a = r.read_accum(); c = r.counters()
+    assert c.iterations == spp * 2 * (5 + 3), c.iterations             # both sub-pipelines ran, each exactly max_depth + 3 iterations
+    r.clear(); r.render(spp, seed=3); b = r.read_accum()
+    assert np.all(a[..., 3] == spp) and np.array_equal(a[..., 3], b[..., 3]) and np.allclose(a, b, rtol=2e-5, atol=1e-5)
+    total = np.zeros_like(a)
+    for rank in range(3):
+        r.clear()
+        for f in range(spp):
+            r.render_tiles(1, 3, f, 3, rank)
+        total += r.read_accum()
+    assert np.array_equal(total[..., 3], a[..., 3]) and np.allclose(total, a, rtol=2e-5, atol=1e-5)
+    r.clear(); r.render(1, seed=3, first_sample=0); one = r.read_accum(); r.close()
+    cpu, _, _ = orc.Oracle(scene, max_depth=5, flags=flags).render(1, seed=3)
+    assert np.all(one[..., 3] == 1) and _frac_beyond(one[..., :3], cpu[..., :3]) <= 0.01
+    # unbounded depth has no known length: the polled loop still ends
+    r = pkg.Renderer(scene, max_depth=0); r.render(1, seed=3); u = r.read_accum(); r.close()
+    assert np.all(u[..., 3] == 1) and np.isfinite(u).all()
+
+
 def test_two_triangle_scene_and_explicit_item_sizes(pkg, orc):
     """Smallest scene the builders accept (one light quad = a single leaf under an artificial root), with and without the device
     BVH flag (which falls back to the host path for <= 2 triangles), and explicit samples_per_item values around the automatic one."""
