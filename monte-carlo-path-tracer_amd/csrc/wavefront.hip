@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t wave_first(uint32_t v) { return __builtin_am
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_kernel(DevScene sc, RenderParams p, PathPool pool, IterCtl* ctl, uint32_t it, uint32_t n_items,
                                                               float4* __restrict__ accum, DevCounters* gcnt) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave index: scalar
     const uint32_t base = blockIdx.x * WF_SHADE_BLOCK;                             // pool.P is a multiple of WF_SHADE_BLOCK
     if (base + tid == 0) { const uint32_t n = (it + 1) & 3; ctl->trace_head[n] = 0; ctl->any_active[n] = 0; }
     __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64];

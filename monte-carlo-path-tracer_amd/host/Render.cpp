@@ -37,15 +37,33 @@ void Render::create(Model& m, const mcpt_opts& opts) {
 }
 Render::Render(Model& m) { mcpt_opts o; std::memset(&o, 0, sizeof o); o.struct_size = sizeof o; create(m, o); }
 Render::Render(Model& m, const mcpt_opts& opts) { create(m, opts); }
-Render::~Render() { if (ctx) mcpt_destroy(ctx); }
+Render::~Render() {
+    if (target) { flush_into(*target); target->detach(this); }
+    if (ctx) mcpt_destroy(ctx);
+}
 
 void Render::render(Scene& scene) { render(scene, 1); }
 void Render::render(Scene& scene, uint32_t spp) {
     if (!ctx || spp == 0) return;
-    // the film lives in `scene` (several Renders may share one Scene): render into a cleared device film, add it
-    if (mcpt_clear_accum(ctx) != MCPT_OK || mcpt_render(ctx, spp, seed, next_sample) != MCPT_OK || mcpt_read_accum(ctx, film.data()) != MCPT_OK) {
-        std::cerr << "Error: mcpt_render: " << mcpt_last_error() << std::endl; return;
+    if (scene.width() * scene.height() * 4 != int(film.size())) { std::cerr << "Error: Render::render: the Scene's size differs from the camera's" << std::endl; return; }
+    // the film lives in `scene` (several Renders may share one Scene); this Render's share of it stays on the device until read
+    if (target != &scene) {
+        if (target) { flush_into(*target); target->detach(this); }
+        target = &scene;
     }
-    next_sample += spp;
+    scene.attach(this);                               // (flushes whichever other Render held samples for `scene`)
+    if (mcpt_render(ctx, spp, seed, next_sample) != MCPT_OK) { std::cerr << "Error: mcpt_render: " << mcpt_last_error() << std::endl; return; }
+    next_sample += spp; dirty = true;
+}
+void Render::flush_into(Scene& scene) {
+    if (!ctx || !dirty || &scene != target) return;
+    dirty = false;
+    if (mcpt_read_accum(ctx, film.data()) != MCPT_OK || mcpt_clear_accum(ctx) != MCPT_OK) { std::cerr << "Error: film read-back: " << mcpt_last_error() << std::endl; return; }
     scene.add_film(film.data());
+}
+void Render::scene_gone(Scene& scene) {
+    if (&scene != target) return;
+    target = nullptr;
+    if (ctx && dirty && mcpt_clear_accum(ctx) != MCPT_OK) std::cerr << "Error: mcpt_clear_accum: " << mcpt_last_error() << std::endl;
+    dirty = false;
 }

@@ -24,7 +24,16 @@ void Scene::add_film(const float* f) {
         m_Pixels[i].color.x += f[4 * i]; m_Pixels[i].color.y += f[4 * i + 1]; m_Pixels[i].color.z += f[4 * i + 2]; m_Pixels[i].spp += f[4 * i + 3];
     }
 }
+Scene::~Scene() { if (m_source) m_source->scene_gone(*this); }
+void Scene::attach(FilmSource* source) {
+    if (m_source == source) return;
+    sync();
+    m_source = source;
+}
+void Scene::detach(FilmSource* source) { if (m_source == source) m_source = nullptr; }
+void Scene::sync() { if (m_source) m_source->flush_into(*this); }
 const Color3b* Scene::getPixelsColor() {
+    sync();
     for (size_t i = 0; i < size_t(w) * h; i++) {
         const float c[3] = {m_Pixels[i].color.x / m_Pixels[i].spp, m_Pixels[i].color.y / m_Pixels[i].spp, m_Pixels[i].color.z / m_Pixels[i].spp};
         uint8_t o[3];

@@ -109,25 +109,36 @@ int main(int argc, char** argv) {
     std::vector<float> film(size_t(w) * h * 4);
     std::atomic<int> failed{0};                       // any device error or failed collective: no image, non-zero exit
     auto fail_with = [&](const std::string& what) { std::cerr << "Error: " << what << std::endl; failed.store(1); };
+    // The films stay on the devices from batch to batch (the reference's loop reads its film every frame only to display it): per batch
+    // one mcpt_render per device, at the end the path's one exchange step and one read-back.
     while (frame < spp && !failed.load()) {
         const uint32_t n = std::min(batch, spp - frame);
         auto t0 = std::chrono::steady_clock::now();
         // sample range [frame, frame+n) split contiguously over the devices; one host thread per device (mcpt_render blocks
         // until its device's work is enqueued and nearly finished)
-        std::vector<std::thread> th;
-        for (uint32_t g = 0; g < gpus; g++) th.emplace_back([&, g]() {
+        auto work = [&](uint32_t g) {
             const uint32_t lo = frame + uint32_t(uint64_t(n) * g / gpus), hi = frame + uint32_t(uint64_t(n) * (g + 1) / gpus);
             mcpt_ctx* c = renders[g]->handle();
-            if (mcpt_clear_accum(c) != MCPT_OK) return fail_with(std::string("mcpt_clear_accum: ") + mcpt_last_error());
             // --shard tiles: device g renders ALL n samples of its interleaved share of the 8x8 tiles (BASELINE.json's "pixel-tile shard");
             // default: its contiguous share of the sample range for every pixel.  Either way the films add up to the frame.
             const mcpt_status rs = shard_tiles ? mcpt_render_tiles(c, n, seed, frame, gpus, g) : (hi > lo ? mcpt_render(c, hi - lo, seed, lo) : MCPT_OK);
             if (rs != MCPT_OK) return fail_with(std::string("mcpt_render: ") + mcpt_last_error());
             if (mcpt_sync(c) != MCPT_OK) return fail_with(std::string("mcpt_sync: ") + mcpt_last_error());
-        });
-        for (auto& t : th) t.join();
+        };
+        if (gpus == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t g = 0; g < gpus; g++) th.emplace_back(work, g);
+            for (auto& t : th) t.join();
+        }
         if (failed.load()) break;
-        if (gpus > 1) {                               // the path's one exchange step: sum of the per-device films over xGMI
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        total_s += s; frame += n;
+        std::cout << "frame: " << frame << "    frame cost: " << s << "s\n";                       // main.cpp:31
+    }
+    if (!failed.load()) {
+        auto t0 = std::chrono::steady_clock::now();
+        if (gpus > 1) {                               // sum of the per-device films over xGMI
             bool ok = ncclGroupStart() == ncclSuccess;
             for (uint32_t g = 0; g < gpus && ok; g++) {
                 void* p = nullptr;
@@ -136,13 +147,13 @@ int main(int argc, char** argv) {
             }
             ok = (ncclGroupEnd() == ncclSuccess) && ok;
             for (uint32_t g = 0; g < gpus && ok; g++) ok = hipSetDevice(int(g)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-            if (!ok) { fail_with("RCCL all-reduce of the films failed"); break; }
+            if (!ok) fail_with("RCCL all-reduce of the films failed");
         }
-        if (mcpt_read_accum(renders[0]->handle(), film.data()) != MCPT_OK) { fail_with(std::string("mcpt_read_accum: ") + mcpt_last_error()); break; }
-        scene.add_film(film.data());
-        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        total_s += s; frame += n;
-        std::cout << "frame: " << frame << "    frame cost: " << s << "s\n";                       // main.cpp:31
+        if (!failed.load()) {
+            if (mcpt_read_accum(renders[0]->handle(), film.data()) != MCPT_OK) fail_with(std::string("mcpt_read_accum: ") + mcpt_last_error());
+            else scene.add_film(film.data());
+        }
+        total_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     if (gpus > 1) for (auto& c : comms) (void)ncclCommDestroy(c);
     if (failed.load()) { for (auto r : renders) delete r; return 1; }

@@ -813,6 +813,38 @@ def test_single_sample_calls_split_tiles_over_both_sub_pipelines(pkg, orc):
     assert np.all(u[..., 3] == 1) and np.isfinite(u).all()
 
 
+def test_facade_classes_keep_the_film_on_the_device_until_it_is_read(pkg, tmp_path):
+    """host/Render + host/Scene used the way the reference's main.cpp uses its classes: render(scene) once per sample, film read at the
+    end.  The samples stay in HBM between calls (Scene::attach / sync); two Renders sharing a Scene, a Scene that dies with unread
+    samples and a Render that dies before its Scene are all folded in correctly.  Checked sample for sample against the C ABI."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "monte-carlo-path-tracer_amd", "csrc"); host = os.path.join(root, "monte-carlo-path-tracer_amd", "host")
+    exe = str(tmp_path / "facade_main")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + host, os.path.join(root, "tests", "facade_main.cpp"),
+                           os.path.join(csrc, "libmcpt_host.a"), "-o", exe, "-L" + csrc, "-lmcpt_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz", "-lpthread",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+    scene = pkg.scenes.cornell_box_small(40, 24)
+    obj = scene.write(str(tmp_path / "scene"))
+    q = lambda a: np.array([[float("%.9g" % x) for x in row] for row in a])          # the file holds 9 significant digits
+    scene = pkg.scenes.SceneData(scene.name, q(scene.vertex), q(scene.normal), q(scene.texcoord), scene.face, scene.materials, scene.camera)
+    frames, depth = 5, 4
+    out = str(tmp_path / "film.bin")
+    line = subprocess.check_output([exe, obj, str(frames), str(depth), out], timeout=300).decode().split("\n")[-2].split()
+    got = np.fromfile(out, np.float32).reshape(24, 40, 4)
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    r = pkg.Renderer(scene, max_depth=depth, flags=flags)
+    for f in list(range(frames)) + [frames + 2]:
+        r.render(1, seed=11, first_sample=f)
+    r.render(2, seed=12, first_sample=0)
+    want = r.read_accum(); r.close()
+    want[0, 0, :3] += (0.25, 0.5, 0.75); want[0, 0, 3] += 1
+    assert np.array_equal(got[..., 3], want[..., 3]) and got[1, 1, 3] == frames + 3
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-5)
+    m = np.clip(want[0, 0, :3] / want[0, 0, 3], 0, 1)
+    assert [int(x) for x in line[2:5]] == [int(v) for v in (np.sqrt(m) * 255.99).astype(np.uint8)]   # Scene::getPixelsColor (Scene.cpp:25-29)
+
+
 def test_two_triangle_scene_and_explicit_item_sizes(pkg, orc):
     """Smallest scene the builders accept (one light quad = a single leaf under an artificial root), with and without the device
     BVH flag (which falls back to the host path for <= 2 triangles), and explicit samples_per_item values around the automatic one."""
