@@ -15,7 +15,10 @@
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <charconv>
 #include <sstream>
+#include <system_error>
+#include <thread>
 #include <zlib.h>
 
 namespace {
@@ -138,38 +141,166 @@ Color3f Texture::get_color(const dvec2& uv) const {
     return image_color.at(size_t(int(v * image_h)) * image_w + int(u * image_w));
 }
 
+// ---- OBJ text.  One line = one record, classified exactly like the reference's chain of `starts_with` tests (model.cpp:62-155).  The
+// records of a multi-million-triangle file are parsed by all host cores: the text is cut into chunks at line ends, every chunk is
+// parsed on its own (numbers through std::from_chars when a token is plain decimal -- [-]digits[.digits][e[+-]digits] -- and through
+// the same istringstream extraction as before for anything else, so odd tokens keep their stream semantics: "+1", "1.5abc", "nan",
+// overflow ...), and the chunks are stitched together in file order.  `mtllib` and `usemtl` lines are order-dependent (a usemtl
+// resolves against the file's materials, model.cpp:131-136): chunks only record them, the stitching replays them in order.
+namespace {
+struct ObjEvent { bool is_mtllib; std::string text; };          // mtllib: the rest of the line; usemtl: the rest of the line
+struct ObjChunk {
+    std::vector<dvec3> vertex, normal;
+    std::vector<dvec2> texture;
+    std::vector<imat3x4> face;
+    std::vector<int> face_event;                                 // per face: index into `events` of the usemtl in force, -1 = inherited
+    std::vector<ObjEvent> events;
+    int last_usemtl = -1;
+};
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
+// plain decimal token at p (after optional blanks), fully consumed and followed by a blank or the end of the line
+inline bool fast_double(const char*& p, const char* e, double& out) {
+    while (p < e && is_space(*p)) p++;
+    const char* t = p;
+    while (t < e && !is_space(*t)) t++;
+    if (t == p || *p == '+') return false;
+    for (const char* c = p; c < t; c++) if (!((*c >= '0' && *c <= '9') || *c == '.' || *c == '-' || *c == '+' || *c == 'e' || *c == 'E')) return false;
+    const auto r = std::from_chars(p, t, out);
+    if (r.ec != std::errc() || r.ptr != t) return false;
+    p = t;
+    return true;
+}
+inline bool fast_int(const char*& p, const char* e, int& out) {
+    if (p < e && *p == '+') return false;
+    const auto r = std::from_chars(p, e, out);
+    if (r.ec != std::errc() || r.ptr == p) return false;
+    p = r.ptr;
+    return true;
+}
+void slow_vec(const std::string& line, size_t skip, int n, double* out) {       // the stream extraction the loader always used
+    std::istringstream ss(rest(line, skip));
+    for (int i = 0; i < n; i++) ss >> out[i];
+}
+bool slow_face(const std::string& line, bool reference_index_order, imat3x4& f) {
+    std::istringstream ss(rest(line, 2)); bool good = true;
+    for (int i = 0; i < 3 && good; i++) {
+        int a = 0, b = 0, c = 0; char s1 = 0, s2 = 0;
+        ss >> a >> s1 >> b >> s2 >> c;
+        good = bool(ss) && s1 == '/' && s2 == '/';
+        f[i][0] = a - 1;
+        if (reference_index_order) { f[i][1] = b - 1; f[i][2] = c - 1; }   // reference: second = normal, third = texcoord
+        else { f[i][1] = c - 1; f[i][2] = b - 1; }                          // Wavefront: v / vt / vn
+        f[i][3] = 0;
+    }
+    return good;
+}
+void parse_obj_chunk(const char* b, const char* e, bool reference_index_order, ObjChunk& out) {
+    static const bool slow_only = std::getenv("MCPT_LOADER_SLOW") != nullptr;   // developer knob: every record through the stream extraction (tests compare)
+    const char* p = b;
+    while (p < e) {
+        const char* le = static_cast<const char*>(std::memchr(p, '\n', size_t(e - p)));
+        const char* next = le ? le + 1 : e;
+        if (!le) le = e;
+        if (le > p && le[-1] == '\r') le--;
+        const size_t n = size_t(le - p);
+        auto begins = [&](const char* t, size_t tn) { return n >= tn && std::memcmp(p, t, tn) == 0; };
+        if (begins("mtllib", 6)) out.events.push_back({true, std::string(p + 6, le)});
+        else if (begins("v ", 2)) {
+            dvec3 v; const char* q = p + 2;
+            if (slow_only || !(fast_double(q, le, v.x) && fast_double(q, le, v.y) && fast_double(q, le, v.z))) { v = dvec3(); slow_vec(std::string(p, le), 2, 3, &v.x); }
+            out.vertex.push_back(v);
+        } else if (begins("vn", 2)) {
+            dvec3 v; const char* q = p + std::min<size_t>(3, n);
+            if (slow_only || !(fast_double(q, le, v.x) && fast_double(q, le, v.y) && fast_double(q, le, v.z))) { v = dvec3(); slow_vec(std::string(p, le), 3, 3, &v.x); }
+            out.normal.push_back(v);
+        } else if (begins("vt", 2)) {
+            dvec2 v; const char* q = p + std::min<size_t>(3, n);
+            if (slow_only || !(fast_double(q, le, v.x) && fast_double(q, le, v.y))) { v = dvec2(); slow_vec(std::string(p, le), 3, 2, &v.x); }
+            out.texture.push_back(v);
+        } else if (begins("usemtl", 6)) { out.last_usemtl = int(out.events.size()); out.events.push_back({false, std::string(p + 6, le)}); }
+        else if (begins("f ", 2)) {
+            imat3x4 f; const char* q = p + 2; bool fast = !slow_only;
+            for (int i = 0; i < 3 && fast; i++) {
+                while (q < le && is_space(*q)) q++;
+                int a = 0, b2 = 0, c = 0;
+                fast = fast_int(q, le, a) && q < le && *q == '/' && fast_int(++q, le, b2) && q < le && *q == '/' && fast_int(++q, le, c) && (q == le || is_space(*q));
+                f[i][0] = a - 1;
+                if (reference_index_order) { f[i][1] = b2 - 1; f[i][2] = c - 1; } else { f[i][1] = c - 1; f[i][2] = b2 - 1; }
+                f[i][3] = 0;
+            }
+            if (!fast) fast = slow_face(std::string(p, le), reference_index_order, f);
+            if (fast) { out.face.push_back(f); out.face_event.push_back(out.last_usemtl); }
+        }
+        p = next;
+    }
+}
+}  // namespace
+
 Model::Model(const std::string& filename, bool reference_index_order) {
     std::cout << "[Model] " << filename << std::endl;
-    std::ifstream file(filename);
-    if (!file.is_open()) { std::cerr << "Error: Cannot open OBJ file: " << filename << std::endl; return; }
+    std::error_code ec;
+    if (!std::filesystem::is_regular_file(filename, ec) || ec) { std::cerr << "Error: Cannot open OBJ file: " << filename << std::endl; return; }
+    const std::string text = read_file<std::string>(filename);
     const std::string parent = dir_of(filename);
-    std::string line; int cur_mtl = 0;
-    while (std::getline(file, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (starts(line, "mtllib")) {
-            std::istringstream ss(rest(line, 6)); std::string name; ss >> name;
+    // ---- cut at line ends, parse the chunks side by side
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
+    const size_t n_chunks = std::max<size_t>(1, std::min<size_t>(std::min(hw, 32u), text.size() / (size_t(1) << 20)));
+    std::vector<size_t> cut(n_chunks + 1, text.size());
+    cut[0] = 0;
+    for (size_t k = 1; k < n_chunks; k++) {
+        size_t at = std::max(cut[k - 1], text.size() * k / n_chunks);
+        const size_t nl = text.find('\n', at);
+        cut[k] = nl == std::string::npos ? text.size() : nl + 1;
+    }
+    std::vector<ObjChunk> chunks(n_chunks);
+    auto work = [&](size_t k) { parse_obj_chunk(text.data() + cut[k], text.data() + cut[k + 1], reference_index_order, chunks[k]); };
+    {
+        std::vector<std::thread> pool;
+        std::vector<char> started(n_chunks, 0);
+        for (size_t k = 1; k < n_chunks; k++) {
+            try { pool.emplace_back(work, k); started[k] = 1; } catch (const std::system_error&) {}    // no thread to be had: parsed below, in line
+        }
+        work(0);
+        for (size_t k = 1; k < n_chunks; k++) if (!started[k]) work(k);
+        for (auto& t : pool) t.join();
+    }
+    // ---- stitch in file order; replay mtllib / usemtl
+    size_t nv = 0, nn = 0, nt = 0, nf = 0;
+    for (const ObjChunk& c : chunks) { nv += c.vertex.size(); nn += c.normal.size(); nt += c.texture.size(); nf += c.face.size(); }
+    vertex.reserve(nv); normal.reserve(nn); texture.reserve(nt); face.reserve(nf);
+    // the reference reads every line first and resolves `usemtl` afterwards (model.cpp:62-92 then :125-136): a usemtl names a material
+    // of ANY mtllib line of the file, also a later one; an unknown name is material 0 (`material_map[name]` default-inserts 0)
+    for (const ObjChunk& c : chunks)
+        for (const ObjEvent& ev : c.events) {
+            if (!ev.is_mtllib) continue;
+            std::istringstream ss(ev.text); std::string name; ss >> name;
             if (name.size() > 3) {
                 std::string xml = name; xml.replace(xml.size() - 3, 3, "xml");
-                loadCameraFromXML(parent + "/" + xml);          // camera first: radiance is attached while materials load (model.cpp:71-72)
+                loadCameraFromXML(parent + "/" + xml);              // camera first: radiance is attached while materials load (model.cpp:71-72)
                 load_material(parent + "/" + name);
             }
-        } else if (starts(line, "v ")) { dvec3 v; std::istringstream ss(rest(line, 2)); ss >> v.x >> v.y >> v.z; vertex.push_back(v); }
-        else if (starts(line, "vn")) { dvec3 n; std::istringstream ss(rest(line, 3)); ss >> n.x >> n.y >> n.z; normal.push_back(n); }
-        else if (starts(line, "vt")) { dvec2 t; std::istringstream ss(rest(line, 3)); ss >> t.x >> t.y; texture.push_back(t); }
-        else if (starts(line, "usemtl")) { std::istringstream ss(rest(line, 6)); std::string name; ss >> name; auto it = material_map.find(name); cur_mtl = it == material_map.end() ? 0 : it->second; }
-        else if (starts(line, "f ")) {
-            std::istringstream ss(rest(line, 2)); imat3x4 f; bool good = true;
-            for (int i = 0; i < 3 && good; i++) {
-                int a = 0, b = 0, c = 0; char s1 = 0, s2 = 0;
-                ss >> a >> s1 >> b >> s2 >> c;
-                good = bool(ss) && s1 == '/' && s2 == '/';
-                f[i][0] = a - 1;
-                if (reference_index_order) { f[i][1] = b - 1; f[i][2] = c - 1; }   // reference: second = normal, third = texcoord
-                else { f[i][1] = c - 1; f[i][2] = b - 1; }                          // Wavefront: v / vt / vn
-                f[i][3] = cur_mtl;
-            }
-            if (good) face.push_back(f);
         }
+    int cur_mtl = 0;
+    for (ObjChunk& c : chunks) {
+        std::vector<int> resolved(c.events.size(), 0);
+        const int carried = cur_mtl;
+        for (size_t i = 0; i < c.events.size(); i++) {
+            if (c.events[i].is_mtllib) continue;
+            std::istringstream ss(c.events[i].text); std::string name; ss >> name;
+            auto it = material_map.find(name);
+            cur_mtl = it == material_map.end() ? 0 : it->second;
+            resolved[i] = cur_mtl;
+        }
+        vertex.insert(vertex.end(), c.vertex.begin(), c.vertex.end());
+        normal.insert(normal.end(), c.normal.begin(), c.normal.end());
+        texture.insert(texture.end(), c.texture.begin(), c.texture.end());
+        for (size_t j = 0; j < c.face.size(); j++) {
+            imat3x4 f = c.face[j];
+            const int m = c.face_event[j] < 0 ? carried : resolved[size_t(c.face_event[j])];
+            f[0][3] = f[1][3] = f[2][3] = m;
+            face.push_back(f);
+        }
+        c = ObjChunk();                                             // free as we go
     }
     ok = !face.empty() && !materials.empty() && camerainfo.width > 0 && camerainfo.height > 0;
 }

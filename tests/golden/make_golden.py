@@ -244,6 +244,7 @@ def loader():
     ref = orc.Reference()
     cases = {"quirk_": os.path.join(HERE, "loader_quirks", "quirk.obj"),
              "jpeg_": os.path.join(HERE, "loader_quirks", "jpeg.obj"),          # map_Kd = a baseline 4:2:0 JPEG: stb_image's decode is the reference here
+             "order_": os.path.join(HERE, "loader_quirks", "order.obj"),        # usemtl before its mtllib line: the reference resolves usemtl after reading the whole file
              "bath_": pkg.scenes.bathroom_stress(64, 36, detail=12, tex_size=32).write(tempfile.mkdtemp(prefix="mcpt_golden_"))}
     for tag, path in cases.items():
         m = ref.parse_model(path)

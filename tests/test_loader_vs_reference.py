@@ -94,6 +94,15 @@ def test_jpeg_texture_decodes_like_the_references_stb_image(tmp_path):
     assert np.allclose(mine["texels"][1], ref["texels"][1])                # the constant-colour material beside it
 
 
+def test_usemtl_resolves_against_the_whole_file_like_the_reference(tmp_path):
+    """order.obj names a material before the `mtllib` line that defines it.  The reference reads every line first and resolves usemtl
+    afterwards (model.cpp:62-92, then :125-136), so the first face gets material `second` (1), not 0; an unknown name is 0."""
+    ref = _golden("order_")
+    mine = _dump(os.path.join(G, "loader_quirks", "order.obj"), tmp_path)
+    _compare(mine, ref, "order")
+    assert [int(x) for x in ref["face"][:, 0, 3]] == [1, 0, 0, 2]
+
+
 def test_wavefront_order_swaps_the_two_attribute_indices(tmp_path):
     a = _dump(QUIRK, tmp_path, ref_order=True)["face"]; b = _dump(QUIRK, tmp_path, ref_order=False)["face"]
     assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 1], b[..., 2]) and np.array_equal(a[..., 2], b[..., 1])
@@ -110,7 +119,7 @@ def test_live_against_the_compiled_reference(pkg, orc, tmp_path):
         ref = orc.Reference()
     except orc.ReferenceUnavailable:
         pytest.skip("oracle/_ref not built here")
-    for obj in (QUIRK, pkg.scenes.cornell_box_small(32, 32).write(str(tmp_path / "cs")), pkg.scenes.veach_mis(32, 18, light_lon=8, light_lat=4, plate_cells=2).write(str(tmp_path / "vm"))):
+    for obj in (QUIRK, os.path.join(G, "loader_quirks", "order.obj"), pkg.scenes.cornell_box_small(32, 32).write(str(tmp_path / "cs")), pkg.scenes.veach_mis(32, 18, light_lon=8, light_lat=4, plate_cells=2).write(str(tmp_path / "vm"))):
         m = ref.parse_model(obj)
         m["size"] = np.array([m["width"], m["height"]])
         _compare(_dump(obj, tmp_path), m, obj)
