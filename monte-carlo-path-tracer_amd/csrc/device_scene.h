@@ -84,6 +84,7 @@ struct DevScene {
     const int32_t* tri_face;
     const DevMaterial* mats;
     const DevLight* lights;
+    const double* light_pos64;     // 9 doubles / light: the fp64 corners of lights[i].tri again, contiguous (no lights[i].tri -> tri_pos64 chain)
     const float4* texels;
     DevCamera cam;
     int32_t n_tris, n_lights, n_nodes, n_mats, n_nodes4;
@@ -102,6 +103,8 @@ struct RenderParams {
     uint32_t integrator;
     uint32_t seed_lo, seed_hi;
     uint32_t atomic_accum;         // 1: several items per pixel -> float atomics; 0: plain read-modify-write
+    uint32_t priv_items;           // wavefront: shade block b alone owns priv_items work items (64-item units k * n_blocks + b: no atomics);
+    uint32_t shared_base;          //   items from shared_base on are handed out through the shared cursors (load balance at the end of a call)
     uint32_t probe_n;              // mcpt_probe_paths through the wavefront pipeline: item i (< probe_n) = "pixel" i of an n x 1 film,
     const double* probe_o;         //   whose one sample starts from the caller's ray (probe_o/probe_d: 3 doubles each) instead of
     const double* probe_d;         //   cast_Ray.  All three are 0 in a render.

@@ -29,7 +29,7 @@ struct mcpt_ctx {
     int device = 0;
     mcpt_opts opts{};
     DevScene dev{};
-    DevBuf nodes, nodes4, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, texels, accum_own, counters;
+    DevBuf nodes, nodes4, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, light_pos64, texels, accum_own, counters;
     float4* accum = nullptr;           // bound accumulator (own or external)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -84,7 +84,7 @@ void destroy_ctx(mcpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->nodes.free_(); c->nodes4.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_plane64.free_(); c->tri_face.free_();
-    c->mats.free_(); c->lights.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
+    c->mats.free_(); c->lights.free_(); c->light_pos64.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
     for (auto& L : c->lanes) {
         for (auto& b : L.pool_bufs) b.free_();
         L.ctl_buf.free_(); L.ovf_buf.free_();
@@ -211,6 +211,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if ((e = upload(c->tri_face, hs.tri_face)) != hipSuccess) return bail(e, "upload tri_face");
     if ((e = upload(c->mats, hs.mats)) != hipSuccess) return bail(e, "upload materials");
     if ((e = upload(c->lights, hs.lights)) != hipSuccess) return bail(e, "upload lights");
+    if ((e = upload(c->light_pos64, hs.light_pos64)) != hipSuccess) return bail(e, "upload light corners");
     if ((e = upload(c->texels, hs.texels)) != hipSuccess) return bail(e, "upload texels");
     const size_t accum_bytes = size_t(c->width) * c->height * sizeof(float4);
     if ((e = c->accum_own.alloc(accum_bytes)) != hipSuccess) return bail(e, "alloc accumulator");
@@ -250,12 +251,12 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             c->lanes.resize(n_lanes);
             for (auto& L : c->lanes) {
                 L.pool.P = P;
-                L.pool_bufs.resize(12);
-                void** dst[12] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sq_d, (void**)&L.pool.nee,
+                L.pool_bufs.resize(13);
+                void** dst[13] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sq_d, (void**)&L.pool.nee,
                                   (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
-                                  (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o};
-                for (int i = 0; i < 12; i++) {
-                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : size_t(P) * 16;
+                                  (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o, (void**)&L.pool.block_items};
+                for (int i = 0; i < 13; i++) {
+                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : i == 12 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint2) : size_t(P) * 16;
                     if ((e = L.pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
                     if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
                     *dst[i] = L.pool_bufs[i].p;
@@ -278,7 +279,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes4 = static_cast<const float4*>(c->nodes4.p); d.n_nodes4 = int32_t(hs.nodes4.size() / 4); d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
     d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p); d.tri_plane64 = static_cast<const double*>(c->tri_plane64.p);
     d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
-    d.lights = static_cast<const DevLight*>(c->lights.p); d.texels = static_cast<const float4*>(c->texels.p);
+    d.lights = static_cast<const DevLight*>(c->lights.p); d.light_pos64 = static_cast<const double*>(c->light_pos64.p); d.texels = static_cast<const float4*>(c->texels.p);
     d.cam = hs.cam;
     d.n_tris = int32_t(hs.tri_face.size()); d.n_lights = int32_t(hs.lights.size()); d.n_nodes = int32_t(hs.nodes.size() / 4); d.n_mats = int32_t(hs.mats.size());
 
@@ -287,7 +288,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     in.n_tris = uint32_t(d.n_tris); in.n_lights = uint32_t(d.n_lights); in.n_nodes = uint32_t(d.n_nodes);
     in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
     in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes + c->mats.bytes +
-                      c->lights.bytes + c->texels.bytes + accum_bytes;
+                      c->lights.bytes + c->light_pos64.bytes + c->texels.bytes + accum_bytes;
     for (auto& L : c->lanes) for (auto& b : L.pool_bufs) in.device_bytes += b.bytes;
     in.bvh_build_ms = hs.bvh_build_ms;
     in.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -348,7 +349,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
     const bool debug = env_u32("MCPT_WF_DEBUG", 0) != 0;
     const uint32_t max_it = env_u32("MCPT_WF_MAXIT", 1u << 20);
     DevCounters* cnt = static_cast<DevCounters*>(ctx->counters.p);
-    struct Run { RenderParams p; PathPool pool; uint32_t n_items = 0, it = 0, issued = 0, seen = 0, bound = 0, snap_it[RING] = {0}; size_t kev = 0; bool active = false, done = false; };
+    struct Run { RenderParams p; PathPool pool; uint32_t n_items = 0, n_shared = 0, it = 0, issued = 0, seen = 0, bound = 0, snap_it[RING] = {0}; size_t kev = 0; bool active = false, done = false; };
     std::vector<Run> runs(n_lanes);
     uint32_t n_active = 0;
     // A call with fewer samples than sub-pipelines (the reference's one-sample-per-call loop, Render.cpp:56-69) splits its TILES over them
@@ -377,6 +378,16 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
         // depth limit ends the path by iteration max_depth + 1 and a parked NEE term (SLOT_DRAIN) costs one more.  The loop then runs
         // exactly that many iterations before it looks at the control block for the first time -- no launches past the end of the job.
         if (r.n_items <= r.pool.P && r.p.chunks == 1 && r.p.samples_per_item == 1 && p0.max_depth != 0 && !p0.probe_n) r.bound = p0.max_depth + 3;
+        // Work items: 90 % are split evenly into one private range per shade block -- the block advances a cursor only it touches, so
+        // the returning atomic that used to sit between two barriers of every block is gone from the steady state -- and the last
+        // 10 % still come from the shared cursors, which is what balances the blocks at the end of the call.
+        r.p.priv_items = 0; r.p.shared_base = 0; r.n_shared = r.n_items;
+        const uint32_t n_blocks = r.pool.P / WF_SHADE_BLOCK;
+        if (!p0.probe_n && uint64_t(r.n_items) >= 4ull * r.pool.P && env_u32("MCPT_WF_PRIVATE_ITEMS", 1)) {
+            r.p.priv_items = uint32_t(0.9 * double(r.n_items) / double(n_blocks)) & ~63u;   // whole 64-item units (block b owns unit k * n_blocks + b)
+            r.p.shared_base = n_blocks * r.p.priv_items;
+            r.n_shared = r.n_items - r.p.shared_base;
+        }
         r.active = true; n_active++;
     }
     for (Run& r : runs) if (r.active) r.p.atomic_accum = ((n_active > 1 && !split_tiles) || r.p.chunks > 1) ? 1u : 0u;
@@ -409,10 +420,10 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             const uint32_t it_of = r.snap_it[k];                           // snapshot taken after iteration it_of
             if (debug && r.seen < 40)
                 fprintf(stderr, "[wf] it=%u active=%u head=%u cursor0=%u/%u\n", it_of, s.any_active[it_of & 3],
-                        s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(r.n_items, 0));
+                        s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(r.n_shared, 0));
             if (s.pad[0]) return fail(MCPT_ERR_HIP, "trace kernel watchdog: a wave did not finish its ray list (internal error)");
             bool items_left = false;
-            for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) items_left |= s.item_cursor[q].v < wf_shard_capacity(r.n_items, q);
+            for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) items_left |= s.item_cursor[q].v < wf_shard_capacity(r.n_shared, q);
             if (s.any_active[it_of & 3] == 0 && !items_left) r.done = true;
             r.seen++;
         }
@@ -436,7 +447,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             }
             const bool timed = ctx->time_kernels && r.it % ctx->time_kernels == 0;
             HIP_TRY(k_event(L, r, timed));
-            HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_items, accum, cnt, L.stream));
+            HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_shared, accum, cnt, L.stream));
             HIP_TRY(k_event(L, r, timed));
             HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(L.ovf_buf.p), L.stream));
             HIP_TRY(k_event(L, r, timed));

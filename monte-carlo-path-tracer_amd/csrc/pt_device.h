@@ -360,7 +360,7 @@ DEV LightData light_fetch(const DevScene& sc, float xi_l) {
     const float4* L = reinterpret_cast<const float4*>(sc.lights + idx);
     LightData d;
     d.a = L[0]; d.b = L[1]; d.c = L[2]; d.e = L[3];
-    const double* P = sc.tri_pos64 + 9 * (size_t)__float_as_int(d.a.x);
+    const double* P = sc.light_pos64 + 9 * (size_t)idx;            // (not tri_pos64[lights[idx].tri]: that would wait for the record)
     d.v0 = ld_d3(P); d.v1 = ld_d3(P + 3); d.v2 = ld_d3(P + 6);
     return d;
 }

@@ -467,7 +467,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     });
 
     // ---- lights in face order (Render.cpp:41-42)
-    out.lights.clear();
+    out.lights.clear(); out.light_pos64.clear();
     for (uint32_t f = 0; f < nf; f++) {
         const int32_t* c = d->face + 12 * size_t(f);
         const mcpt_material& m = d->materials[c[3]];
@@ -482,6 +482,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
             L.n0[a] = float(d->normal[3 * size_t(c[1]) + a]); L.n1[a] = float(d->normal[3 * size_t(c[5]) + a]); L.n2[a] = float(d->normal[3 * size_t(c[9]) + a]);
         }
         out.lights.push_back(L);
+        out.light_pos64.insert(out.light_pos64.end(), out.tri_pos64.begin() + 9 * size_t(L.tri), out.tri_pos64.begin() + 9 * size_t(L.tri) + 9);
     }
     if (out.lights.empty()) { err = "scene has no emissive triangle (|radiance| > 0.01); the reference indexes lights[-1] here"; return MCPT_ERR_NO_LIGHTS; }
 

@@ -20,6 +20,7 @@ struct HostScene {
     std::vector<int32_t> tri_face;   // leaf order -> input face index
     std::vector<DevMaterial> mats;
     std::vector<DevLight> lights;
+    std::vector<double> light_pos64; // 9 per light
     std::vector<f4h> texels;
     DevCamera cam;
     uint32_t bvh_depth = 0, max_leaf = 0, bvh4_depth = 0;

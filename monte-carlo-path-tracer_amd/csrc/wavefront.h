@@ -27,6 +27,7 @@ struct PathPool {
     uint4* ids;         // pixel, current sample index, next sample index, end sample index
     uint32_t* shadow_queue;   // slots with a pending shadow ray: shade block b owns entries [256 b, 256 b + shadow_count[b]) -- no atomics
     uint32_t* shadow_count;   // entries each shade block wrote this iteration
+    uint2* block_items;       // per shade block: {next, end} of its private work-item range (RenderParams::priv_items); the block alone reads and writes it
     uint32_t P;         // slots
 };
 

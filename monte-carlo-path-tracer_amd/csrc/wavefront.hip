@@ -88,9 +88,15 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
                                                               float4* __restrict__ accum, DevCounters* gcnt) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave index: scalar
     const uint32_t base = blockIdx.x * WF_SHADE_BLOCK;                             // pool.P is a multiple of WF_SHADE_BLOCK
+#ifdef WF_SHADE_STATS      // diagnostic build (tools/shade_stats.py): shader-clock cycles of every wave per section of the kernel
+    unsigned long long sh_t[7] = {0, 0, 0, 0, 0, 0, 0}, sh_mark = __builtin_amdgcn_s_memtime();
+#define SH_TICK(I) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); sh_t[I] += t_now - sh_mark; sh_mark = t_now; }
+#else
+#define SH_TICK(I)
+#endif
     if (base + tid == 0) { const uint32_t n = (it + 1) & 3; ctl->trace_head[n] = 0; ctl->any_active[n] = 0; }
     __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64];
-    __shared__ uint32_t s_base, s_sel;
+    __shared__ uint32_t s_base, s_sel, s_priv_base, s_priv_take, s_priv_next, s_priv_end;
     // the whole slot state of the block's 256-slot window, fetched coalesced in ONE batch by the slots' own lanes and handed to the
     // lanes that will process them through LDS: no dependent second round of (gathering) global loads after the sort ...
     __shared__ float4 s_beta[WF_SHADE_BLOCK], s_hit[WF_SHADE_BLOCK], s_L[WF_SHADE_BLOCK], s_rd[WF_SHADE_BLOCK], s_nee[WF_SHADE_BLOCK], s_ro[WF_SHADE_BLOCK];
@@ -113,18 +119,27 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     __shared__ float4 s_lights[WF_LDS_LIGHTS * 4];
     __shared__ double s_light_pos[WF_LDS_LIGHTS * 9];
     const bool mats_lds = sc.n_mats <= WF_LDS_MATS, lights_lds = sc.n_lights <= WF_LDS_LIGHTS;
-    if (mats_lds) for (uint32_t i = tid; i < (uint32_t)sc.n_mats * 4; i += WF_SHADE_BLOCK) s_mats[i] = reinterpret_cast<const float4*>(sc.mats)[i];
-    if (lights_lds) {
-        for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 4; i += WF_SHADE_BLOCK) s_lights[i] = reinterpret_cast<const float4*>(sc.lights)[i];
-        for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 9; i += WF_SHADE_BLOCK) s_light_pos[i] = sc.tri_pos64[9 * (size_t)sc.lights[i / 9].tri + i % 9];
-    }
 
     // ---- classification of the lane's OWN slot (coalesced): which branch will this slot take?
     {
         const float4 bt0 = ld_s(&pool.beta[base + tid]), h0 = ld_s(&pool.hit[base + tid]);
         const uint4 id0 = ld_s(&pool.ids[base + tid]);
-        s_L[tid] = ld_s(&pool.L[base + tid]); s_rd[tid] = ld_s(&pool.ray_d[base + tid]); s_nee[tid] = ld_s(&pool.nee[base + tid]);
-        s_ro[tid] = ld_s(&pool.ray_o[base + tid]);
+        const float4 L0 = ld_s(&pool.L[base + tid]), rd0 = ld_s(&pool.ray_d[base + tid]), nee0 = ld_s(&pool.nee[base + tid]), ro0 = ld_s(&pool.ray_o[base + tid]);
+        // the block's private work-item range: its cursor rides in this batch of loads too (thread 0) and waits in LDS until the item pull
+        uint2 priv = make_uint2(0u, 0u);
+        if (tid == 0 && p.priv_items) {
+            if (it == 0) { priv.x = 0u; priv.y = p.priv_items; }
+            else priv = pool.block_items[blockIdx.x];
+        }
+        // the tables ride in the same batch of loads, behind the slot records (the light corners are a contiguous copy: fetching them
+        // through lights[i].tri was a second, dependent round trip in front of the block's first barrier)
+        if (mats_lds) for (uint32_t i = tid; i < (uint32_t)sc.n_mats * 4; i += WF_SHADE_BLOCK) s_mats[i] = reinterpret_cast<const float4*>(sc.mats)[i];
+        if (lights_lds) {
+            for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 4; i += WF_SHADE_BLOCK) s_lights[i] = reinterpret_cast<const float4*>(sc.lights)[i];
+            for (uint32_t i = tid; i < (uint32_t)sc.n_lights * 9; i += WF_SHADE_BLOCK) s_light_pos[i] = sc.light_pos64[i];
+        }
+        s_L[tid] = L0; s_rd[tid] = rd0; s_nee[tid] = nee0; s_ro[tid] = ro0;
+        if (tid == 0) { s_priv_next = priv.x; s_priv_end = priv.y; }
         s_beta[tid] = bt0; s_hit[tid] = h0; s_ids[tid] = id0;
         const uint32_t st0 = __float_as_uint(bt0.w);
         const int bounce0 = (int)(st0 >> 8), tri0 = __float_as_int(h0.x);
@@ -162,6 +177,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     const uint32_t pk = s_perm[tid];
 #endif
     const uint32_t key = pk >> 16, src = pk & 0xffffu, slot = base + src;
+    SH_TICK(0)                                                                                    // tables + slot records + classification sort
 
     // From here on the slot's LDS cells are the HOME of its state: values are read where a phase needs them and parked again when it is
     // done (the cells belong to this lane alone), so that almost nothing but indices stays in registers across the register-hungry
@@ -223,6 +239,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
             s_hit[src] = mk4(hs.n, hs.tu); s_nee[src] = make_float4(hs.tv, __int_as_float(hs.mat), 0.f, 0.f);
         }
         WF_PHASE();
+        SH_TICK(1)                                                                                // phase 1: hit record gather, emitter MIS
         // ---- phase 2: light sample (Render.cpp:124, :202-223) with the fp64 self-hit predicate of SURVEY A-9
         // The hit point in fp64: ray (fp32 origin the trace kernel used, fp32 direction) x the triangle's fp64 plane.  Like the
         // reference's point (Triangle.cpp:35-38) it lies on that plane to ~1e-16 with full fp64 noise in its low bits -- the two
@@ -246,6 +263,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
             ls = sample_light(ld, p64, ra.v[1], ra.v[2], true);
         }
         WF_PHASE();
+        SH_TICK(2)                                                                                // phase 2: fp64 hit point + light sample
         // ---- phase 3: BSDF (BSDF.cpp:87-110), NEE with MIS (Render.cpp:125-130), BSDF sample (Render.cpp:133-140)
         Bsdf bsdf;
         {
@@ -294,6 +312,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     } while (0);
     else if (state != SLOT_DEAD) terminated = true;                                             // miss (Render.cpp:118-119,144-145) or DRAIN
     WF_PHASE();
+    SH_TICK(3)                                                                                    // phase 3: BSDF, NEE, BSDF sample
     uint4 id = s_ids[src];                                                                      // pixel, sample, s_next, s_end
 
     // one-sample items (the default) flush every finished sample straight to the film: their accumulator record is always zero, so
@@ -323,12 +342,17 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         if (tid == 0) {
             uint32_t tot = 0; for (uint32_t k = 0; k < WF_SHADE_BLOCK / 64; k++) tot += s_wave_cnt[k];
             uint32_t b0 = 0xffffffffu, sel = 0;
-            if (tot) {
+            const uint32_t priv_next = s_priv_next, priv_end = s_priv_end;
+            const uint32_t take = min(tot, priv_end - priv_next);                                 // from the private range: no atomic
+            s_priv_base = priv_next; s_priv_take = take;
+            if (p.priv_items && (take || it == 0)) pool.block_items[blockIdx.x] = make_uint2(priv_next + take, priv_end);
+            const uint32_t rest = tot - take;
+            if (rest) {
                 for (uint32_t probe = 0; probe < 4; probe++) {
                     const uint32_t k = (blockIdx.x + probe * 17u) & (WF_ITEM_SHARDS - 1);
                     const uint32_t cap = wf_shard_capacity(n_items, k);
                     if (__hip_atomic_load(&ctl->item_cursor[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cap) {
-                        const uint32_t b = atomicAdd(&ctl->item_cursor[k].v, tot);
+                        const uint32_t b = atomicAdd(&ctl->item_cursor[k].v, rest);
                         if (b < cap) { b0 = b; sel = k; break; }
                     }
                 }
@@ -338,14 +362,21 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         __syncthreads();
         if (want_item) {
             id.z = id.w = 0; id_dirty = true;
-            if (s_base != 0xffffffffu) {
-                uint32_t before = 0;
-                for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
-                const uint32_t l = s_base + before + lane_rank(m);
-                const uint32_t item = ((l / WF_SHADE_BLOCK) * WF_ITEM_SHARDS + s_sel) * WF_SHADE_BLOCK + (l % WF_SHADE_BLOCK);
+            uint32_t before = 0;
+            for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
+            const uint32_t j = before + lane_rank(m);                       // this lane's rank among the block's requests
+            const bool mine = j < s_priv_take;
+            if (mine || s_base != 0xffffffffu) {
+                const uint32_t l = s_base + (j - s_priv_take);
+                const uint32_t shared_item = ((l / WF_SHADE_BLOCK) * WF_ITEM_SHARDS + s_sel) * WF_SHADE_BLOCK + (l % WF_SHADE_BLOCK);
+                // private item jl of block b = tile-sized unit (jl / 64) * n_blocks + b: every block's range is spread over the whole image,
+                // so all blocks see the same mix of path lengths and use their ranges up at the same pace (contiguous ranges did not:
+                // +2 % iterations at the end of a call, which ate what the missing atomic had saved)
+                const uint32_t jl = s_priv_base + j;
+                const uint32_t item = mine ? ((jl >> 6) * gridDim.x + blockIdx.x) * 64u + (jl & 63u) : p.shared_base + shared_item;
                 if (p.probe_n) {                                            // probe: item = film entry, one sample
                     if (item < p.probe_n) { id.x = item; id.z = p.first_sample; id.w = p.first_sample + 1u; }
-                } else if (item < n_items) {
+                } else if (mine || shared_item < n_items) {
                     const uint32_t n_tiles = p.n_owned;
                     const uint32_t iw = item >> 6, il = item & 63u;
                     const uint32_t chunk = iw / n_tiles, tile = p.tile_rem + (iw - chunk * n_tiles) * p.tile_mod;
@@ -378,6 +409,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         state = SLOT_ALIVE; emit_extend = true; c_prim = true;
     }
 
+    SH_TICK(4)                                                                                    // film write, item pull, camera ray
     // ---- finish the slot's cells: state word, "which records changed" flags
     {
         float4 b4 = s_beta[src];
@@ -415,6 +447,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         if (fl & OUT_SHADOW) st_s(&pool.nee[own], s_nee[tid]);
         if (fl & OUT_IDS) st_s(&pool.ids[own], s_ids[tid]);
     }
+    SH_TICK(5)                                                                                    // shadow-queue append + coalesced stores
     // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
     const uint64_t ma = __ballot(state != SLOT_DEAD);
     const uint64_t m_term = __ballot(terminated), m_prim = __ballot(c_prim), m_cont = __ballot(c_cont);
@@ -437,8 +470,14 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
 #ifndef WF_SCHED_STATS
         if (COUNT) { if (m_shaded) atomicAdd(&g->shaded_hits, (unsigned long long)__popcll(m_shaded)); if (texels) atomicAdd(&g->texel_fetches, texels); }
 #endif
+#ifdef WF_SHADE_STATS
+        SH_TICK(6)
+        atomicAdd(&g->debug[0], sh_t[0]); atomicAdd(&g->debug[1], sh_t[1]); atomicAdd(&g->debug[2], sh_t[2]); atomicAdd(&g->debug[3], sh_t[3]);
+        atomicAdd(&g->box_tests, sh_t[4]); atomicAdd(&g->tri_tests, sh_t[5]); atomicAdd(&g->stack_spills, sh_t[6]); atomicAdd(&g->texel_fetches, 1ull);   // texel_fetches: waves
+#endif
     }
 }
+#undef SH_TICK
 
 // ====================================================================================================== trace
 // BVH_node::hit / has_hit (BVH.cpp:95-136), AABB::Intersection (AABB.cpp:25-36), Triangle::hit / isIntersect
