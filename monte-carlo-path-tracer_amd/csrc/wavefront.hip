@@ -803,6 +803,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = OVF(sp - WF_LDS_STACK); }
                 }
                 WF_PARK_LEAF()
+#ifdef WF_DUMMY_VALU    /* regime probe: N extra VALU issues per inner step (independent of everything, results discarded) */
+                { float dz = idx;
+#pragma unroll
+                  for (int k = 0; k < WF_DUMMY_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dz));
+                  asm volatile("" :: "v"(dz)); }
+#endif
             }
             if (greedy) {                                                  // stay while inner nodes are still what most lanes wait for
                 const int cl = __popcll(__ballot(have && node < 0 && node != MCPT_NODE_SENTINEL)), ci = __popcll(__ballot(have && node >= 0));
