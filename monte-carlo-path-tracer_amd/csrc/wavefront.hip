@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
             const uint32_t rest = tot - take;
             if (rest) {
                 for (uint32_t probe = 0; probe < 4; probe++) {
-                    const uint32_t k = (blockIdx.x + probe * 17u) & (WF_ITEM_SHARDS - 1);
+                    const uint32_t k = (blockIdx.x + (it * 4u + probe) * 17u) & (WF_ITEM_SHARDS - 1);   // (rotates with the iteration: a small grid still visits every shard)
                     const uint32_t cap = wf_shard_capacity(n_items, k);
                     if (__hip_atomic_load(&ctl->item_cursor[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cap) {
                         const uint32_t b = atomicAdd(&ctl->item_cursor[k].v, rest);

@@ -813,6 +813,44 @@ def test_single_sample_calls_split_tiles_over_both_sub_pipelines(pkg, orc):
     assert np.all(u[..., 3] == 1) and np.isfinite(u).all()
 
 
+def test_block_private_work_items_cover_every_sample_once(pkg):
+    """90 % of a call's work items are handed out without atomics: shade block b owns the 64-item units k * n_blocks + b, the rest comes
+    from the shared cursors.  That only happens when a call has at least four items per pool slot -- a small pool (developer knob
+    MCPT_WF_POOL_LOG2) makes a test-sized film qualify.  Every pixel must get every sample exactly once, the film must equal the
+    all-shared hand-out (MCPT_WF_PRIVATE_ITEMS=0) and the default pool's, and interleaved tile shares must still add up."""
+    scene = pkg.scenes.cornell_box_small(136, 88)                       # 17 x 11 tiles: nothing divides evenly
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    spp = 12
+
+    def film(env, shares=None):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            r = pkg.Renderer(scene, max_depth=4, flags=flags)
+            if shares is None:
+                r.render(spp, seed=21); out = r.read_accum()
+            else:
+                out = np.zeros((88, 136, 4), np.float32)
+                for rank in range(shares):
+                    r.clear(); r.render_tiles(spp, 21, 0, shares, rank); out += r.read_accum()
+            r.close()
+            return out
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+
+    ref = film({})                                                      # 2^23-slot pools: everything from the shared cursors
+    assert np.all(ref[..., 3] == spp)
+    for log2 in ("11", "13"):
+        a = film({"MCPT_WF_POOL_LOG2": log2})
+        b = film({"MCPT_WF_POOL_LOG2": log2, "MCPT_WF_PRIVATE_ITEMS": "0"})
+        assert np.all(a[..., 3] == spp) and np.all(b[..., 3] == spp), log2
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-5) and np.allclose(a, ref, rtol=2e-5, atol=1e-5), log2
+    t = film({"MCPT_WF_POOL_LOG2": "11"}, shares=3)
+    assert np.array_equal(t[..., 3], ref[..., 3]) and np.allclose(t, ref, rtol=2e-5, atol=1e-5)
+
+
 def test_facade_classes_keep_the_film_on_the_device_until_it_is_read(pkg, tmp_path):
     """host/Render + host/Scene used the way the reference's main.cpp uses its classes: render(scene) once per sample, film read at the
     end.  The samples stay in HBM between calls (Scene::attach / sync); two Renders sharing a Scene, a Scene that dies with unread
