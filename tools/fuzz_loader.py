@@ -76,7 +76,7 @@ def run(cases, seed, workdir=None, verbose=True):
         rng = random.Random(seed)
         # (model stem, file to corrupt, is text)
         targets = [("quirk", "quirk.obj", True), ("quirk", "quirk.mtl", True), ("quirk", "quirk.xml", True),
-                   ("quirk", "tex.png", False), ("jpeg", "tex.jpg", False)]
+                   ("quirk", "tex.png", False), ("jpeg", "tex.jpg", False), ("order", "order.obj", True), ("order", "order.mtl", True)]
         scene = os.path.join(workdir, "scene")
         for k in range(cases):
             stem, victim, text = targets[k % len(targets)]
