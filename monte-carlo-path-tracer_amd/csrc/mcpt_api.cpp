@@ -113,18 +113,25 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 }
 
 // scratch device buffer for probes
+// Device scratch of one probe / tonemap call.  The fills below go through the legacy default stream, the kernels that use the buffers
+// run on the context's stream, which is NON-BLOCKING (no implicit ordering with the default stream): hipMemset on device memory
+// returns before it has executed, so without the explicit wait a kernel could write its results first and have them zeroed afterwards
+// (seen as black regions in `mcpt_cli --save-every` images: the tonemap kernel ran ahead of its buffer's memset).
 struct Scratch {
     std::vector<void*> ptrs;
     ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
     template <class T> hipError_t in(const T* host, size_t n, T** dev) {
         hipError_t e = hipMalloc((void**)dev, (n ? n : 1) * sizeof(T)); if (e != hipSuccess) return e;
         ptrs.push_back(*dev);
-        return n ? hipMemcpy(*dev, host, n * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
+        if (!n) return hipSuccess;
+        e = hipMemcpy(*dev, host, n * sizeof(T), hipMemcpyHostToDevice); if (e != hipSuccess) return e;
+        return hipStreamSynchronize(nullptr);
     }
     template <class T> hipError_t out(size_t n, T** dev) {
         hipError_t e = hipMalloc((void**)dev, (n ? n : 1) * sizeof(T)); if (e != hipSuccess) return e;
         ptrs.push_back(*dev);
-        return hipMemset(*dev, 0, (n ? n : 1) * sizeof(T));
+        e = hipMemset(*dev, 0, (n ? n : 1) * sizeof(T)); if (e != hipSuccess) return e;
+        return hipStreamSynchronize(nullptr);
     }
 };
 
@@ -547,6 +554,7 @@ mcpt_status mcpt_write_accum(mcpt_ctx* ctx, const float* rgba_host) {
     if (!rgba_host) return fail(MCPT_ERR_INVALID_ARG, "null input");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(ctx->accum, rgba_host, size_t(ctx->width) * ctx->height * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return MCPT_OK;
 }
 mcpt_status mcpt_clear_accum(mcpt_ctx* ctx) {
@@ -592,6 +600,7 @@ mcpt_status mcpt_reset_counters(mcpt_ctx* ctx) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemset(ctx->counters.p, 0, sizeof(DevCounters) * WF_COUNTER_REPLICAS));
+    HIP_TRY(hipStreamSynchronize(nullptr));                          // (default-stream fill vs kernels on the non-blocking context stream: see Scratch)
     st = resolve_timing(ctx); if (st != MCPT_OK) return st;
     ctx->total_kernel_ms = 0.0; ctx->launches = 0; ctx->total_trace_ms = 0.0; ctx->total_shade_ms = 0.0; ctx->total_iterations = 0;
     return MCPT_OK;
@@ -677,6 +686,7 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
     HIP_TRY(hipMemcpy(pool.shadow_queue, queue.data(), queue.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pool.shadow_count, qcount.data(), qcount.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(L.ctl_buf.p, 0, sizeof(IterCtl)));
+    HIP_TRY(hipStreamSynchronize(nullptr));                          // the fills above ran on the default stream; the kernel below does not wait for it by itself
     const bool count = (ctx->opts.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
     HIP_TRY(launch_wf_trace(ctx->dev, pool, static_cast<IterCtl*>(L.ctl_buf.p), 0u, ctx->tune, count, static_cast<DevCounters*>(ctx->counters.p), ctx->trace_grid,
                             static_cast<int*>(L.ovf_buf.p), ctx->stream));

@@ -18,7 +18,7 @@
 
 static void usage() {
     std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--shard samples|tiles] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
-                 "                          [--deterministic] [--ref-index-order] [--gpu-bvh] [--check] [--dump-model file]\n"
+                 "                          [--deterministic] [--ref-index-order] [--gpu-bvh] [--check] [--dump-model file] [--save-every K]\n"
                  "       mcpt_cli --decode-image texture.(png|jpg|ppm) out.ppm\n";
 }
 
@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     std::string filename = argv[1], out, dump_model;
-    uint32_t spp = 64, batch = 0, depth = 0, gpus = 1; uint64_t seed = 20251004; uint32_t flags = 0, integrator = 0; bool ref_order = false, check_only = false, shard_tiles = false;
+    uint32_t spp = 64, batch = 0, depth = 0, gpus = 1, save_every = 0; uint64_t seed = 20251004; uint32_t flags = 0, integrator = 0; bool ref_order = false, check_only = false, shard_tiles = false;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i]; auto next = [&]() { return i + 1 < argc ? argv[++i] : (char*)"0"; };
         if (a == "--spp") spp = uint32_t(std::atoi(next())); else if (a == "--batch") batch = uint32_t(std::atoi(next()));
@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
         else if (a == "--gpu-bvh") flags |= MCPT_FLAG_GPU_BVH_BUILD;
         else if (a == "--check") check_only = true;
         else if (a == "--dump-model") dump_model = next();
+        else if (a == "--save-every") save_every = uint32_t(std::atoi(next()));
         else if (a == "--shard") shard_tiles = std::string(next()) == "tiles";
         else { usage(); return 2; }
     }
@@ -105,7 +106,7 @@ int main(int argc, char** argv) {
         std::vector<int> devs(gpus); for (uint32_t g = 0; g < gpus; g++) devs[g] = int(g);
         if (ncclCommInitAll(comms.data(), int(gpus), devs.data()) != ncclSuccess) { std::cerr << "Error: ncclCommInitAll" << std::endl; return 1; }
     }
-    uint32_t frame = 0; uint64_t rays = 0; double total_s = 0;
+    uint32_t frame = 0, batches_done = 0; uint64_t rays = 0; double total_s = 0;
     std::vector<float> film(size_t(w) * h * 4);
     std::atomic<int> failed{0};                       // any device error or failed collective: no image, non-zero exit
     auto fail_with = [&](const std::string& what) { std::cerr << "Error: " << what << std::endl; failed.store(1); };
@@ -135,6 +136,17 @@ int main(int argc, char** argv) {
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         total_s += s; frame += n;
         std::cout << "frame: " << frame << "    frame cost: " << s << "s\n";                       // main.cpp:31
+        // --save-every K: a progressive image every K batches, like the reference's window shows every frame (main.cpp:33-36) -- tonemapped
+        // on the device (Scene::getPixelsColor as a kernel: mean, clamp, sqrt, x255.99) from device 0's film, 3 bytes per pixel read back;
+        // with several devices that is the image of device 0's share of the samples so far
+        batches_done++;
+        if (save_every && batches_done % save_every == 0 && frame < spp) {
+            std::vector<uint8_t> rgb(size_t(w) * h * 3);
+            if (mcpt_tonemap(renders[0]->handle(), rgb.data(), 1) != MCPT_OK) { fail_with(std::string("mcpt_tonemap: ") + mcpt_last_error()); break; }
+            const std::string file = out + std::to_string(frame) + ".png";
+            if (write_png_rgb8(file, w, h, rgb.data())) std::cout << "Image saved successfully: " << file << std::endl;
+            else std::cerr << "Failed to save image: " << file << std::endl;
+        }
     }
     if (!failed.load()) {
         auto t0 = std::chrono::steady_clock::now();

@@ -576,6 +576,15 @@ def test_cpp_cli_end_to_end(pkg, tmp_path):
     r = pkg.Renderer(s, max_depth=4, flags=pkg.FLAG_DETERMINISTIC); r.render(8, seed=5); want = r.tonemap(flip_y=True); r.close()
     assert png.shape == want.shape
     assert (np.abs(png.astype(int) - want.astype(int)) <= 1).mean() > 0.995   # host powf vs device powf at a rounding edge
+    # --save-every: progressive images from the device film (tonemap kernel + PNG writer), the film itself stays on the device
+    out = subprocess.check_output([cli, obj, "--spp", "8", "--batch", "2", "--save-every", "1", "--depth", "4", "--seed", "5", "--deterministic",
+                                   "--out", str(tmp_path / "prog")]).decode()
+    assert out.count("Image saved successfully") == 4 and all(os.path.exists(str(tmp_path / ("prog%d.png" % k))) for k in (2, 4, 6, 8))
+    r = pkg.Renderer(s, max_depth=4, flags=pkg.FLAG_DETERMINISTIC); r.render(4, seed=5); want4 = r.tonemap(flip_y=True); r.close()
+    p4 = np.asarray(Image.open(str(tmp_path / "prog4.png")))                                    # (2 + 2 samples vs 4 in one call, 9-digit scene file: last-bit film differences)
+    assert p4.shape == want4.shape and (np.abs(p4.astype(int) - want4.astype(int)) <= 1).mean() > 0.995
+    final = np.asarray(Image.open(str(tmp_path / "prog8.png")))
+    assert (np.abs(final.astype(int) - want.astype(int)) <= 1).mean() > 0.995
 
 
 def test_cpp_cli_multi_gpu_path_or_its_failure(pkg, tmp_path):
