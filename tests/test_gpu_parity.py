@@ -860,6 +860,56 @@ def test_block_private_work_items_cover_every_sample_once(pkg):
     assert np.array_equal(t[..., 3], ref[..., 3]) and np.allclose(t, ref, rtol=2e-5, atol=1e-5)
 
 
+def test_random_api_call_sequences_keep_their_invariants(pkg):
+    """A seeded random walk over the C ABI -- render / clear / read / write / tonemap / counters / reset / probes in any order, back to back
+    with no pauses -- checking after every observation what must hold: every pixel has exactly the samples rendered since the last clear,
+    the device tonemap is the tonemap of that film, the path counter is pixels x samples since the last reset, a probe between two renders
+    disturbs nothing, and the final film equals one fresh render of the same sample ranges.  (Found the unordered scratch fills of
+    mcpt_tonemap: a default-stream memset overtaken by the kernel on the context's non-blocking stream.)"""
+    scene = pkg.scenes.cornell_box_small(56, 40)
+    W, H = 56, 40
+    rng = np.random.RandomState(17)
+    rays_o = np.tile(np.array([[0.5, 0.5, 2.0]]), (64, 1)); rays_d = np.tile(np.array([[0.0, 0.0, -1.0]]), (64, 1))
+    for flags in (0, pkg.FLAG_DETERMINISTIC):
+        r = pkg.Renderer(scene, max_depth=4, flags=flags)
+        count, next_sample, ranges, paths_since_reset = 0, 0, [], 0
+        base = np.zeros((H, W, 4), np.float32)                        # what write_accum put under the rendered samples
+        r.reset_counters()
+        for step in range(70):
+            op = rng.choice(["render", "render", "render", "read", "tonemap", "counters", "reset", "clear", "probe", "rewrite"])
+            if op == "render":
+                n = int(rng.choice([1, 1, 2, 3, 5]))
+                r.render(n, seed=9, first_sample=next_sample); ranges.append((next_sample, n)); next_sample += n; count += n; paths_since_reset += n * W * H
+            elif op == "read":
+                a = r.read_accum()
+                assert np.all(a[..., 3] == count + base[..., 3]), (flags, step)
+            elif op == "tonemap":
+                t = r.tonemap(flip_y=True).astype(int); a = r.read_accum()
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    m = np.clip(np.nan_to_num(a[..., :3] / a[..., 3:]), 0, 1)
+                want = (np.sqrt(m) * 255.99).astype(np.uint8)[::-1].astype(int)
+                if count + base[0, 0, 3] > 0:
+                    assert (np.abs(t - want) <= 1).all(), (flags, step)
+            elif op == "counters":
+                assert r.counters().paths == paths_since_reset, (flags, step)
+            elif op == "reset":
+                r.reset_counters(); paths_since_reset = 0
+            elif op == "clear":
+                r.clear(); count = 0; ranges = []; base[:] = 0
+            elif op == "probe":
+                t, tri, _, _ = r.probe_trace4(rays_o, rays_d)
+                assert np.all(tri == tri[0]) and np.all(t > 0)
+            elif op == "rewrite":                                       # read the film, write it back: a no-op for what follows
+                a = r.read_accum(); r.write_accum(a)
+        a = r.read_accum()
+        assert np.all(a[..., 3] == count)
+        fresh = pkg.Renderer(scene, max_depth=4, flags=flags)
+        for first, n in ranges:
+            fresh.render(n, seed=9, first_sample=first)
+        b = fresh.read_accum(); fresh.close(); r.close()
+        assert np.allclose(a, b, rtol=3e-5, atol=1e-5), flags
+
+
 def test_facade_classes_keep_the_film_on_the_device_until_it_is_read(pkg, tmp_path):
     """host/Render + host/Scene used the way the reference's main.cpp uses its classes: render(scene) once per sample, film read at the
     end.  The samples stay in HBM between calls (Scene::attach / sync); two Renders sharing a Scene, a Scene that dies with unread
