@@ -910,6 +910,33 @@ def test_random_api_call_sequences_keep_their_invariants(pkg):
         assert np.allclose(a, b, rtol=3e-5, atol=1e-5), flags
 
 
+def test_two_contexts_render_concurrently_from_two_threads(pkg):
+    """Two contexts on one device, driven from two host threads at the same time (ctypes drops the GIL inside the calls; mcpt_cli --gpus
+    uses one thread per context the same way): same films as when each renders alone."""
+    import threading
+    scenes = [pkg.scenes.cornell_box_small(64, 48), pkg.scenes.open_box(40, 56)]
+    alone = []
+    for sc in scenes:
+        r = pkg.Renderer(sc, max_depth=5); r.render(24, seed=31); alone.append(r.read_accum()); r.close()
+    rs = [pkg.Renderer(sc, max_depth=5) for sc in scenes]
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            for f in range(0, 24, 3):
+                rs[i].render(3, seed=31, first_sample=f)
+            out[i] = rs[i].read_accum()
+        except Exception as e:                                          # noqa: BLE001 -- reported below
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for r in rs: r.close()
+    assert not errs, errs
+    for i in range(2):
+        assert np.array_equal(out[i][..., 3], alone[i][..., 3]) and np.allclose(out[i], alone[i], rtol=3e-5, atol=1e-5), i
+
+
 def test_facade_classes_keep_the_film_on_the_device_until_it_is_read(pkg, tmp_path):
     """host/Render + host/Scene used the way the reference's main.cpp uses its classes: render(scene) once per sample, film read at the
     end.  The samples stay in HBM between calls (Scene::attach / sync); two Renders sharing a Scene, a Scene that dies with unread
