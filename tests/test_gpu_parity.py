@@ -910,6 +910,23 @@ def test_random_api_call_sequences_keep_their_invariants(pkg):
         assert np.allclose(a, b, rtol=3e-5, atol=1e-5), flags
 
 
+def test_extreme_film_shapes(pkg, orc):
+    """1 x 1, a single row, a single column, sizes that are not multiples of the 8 x 8 tile: every pixel gets its samples, nothing is written
+    outside the film (the accumulator has exactly w * h records), and the film matches the oracle's."""
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    for w, h in ((1, 1), (257, 1), (1, 130), (9, 7), (3, 65)):
+        scene = pkg.scenes.open_box(w, h)
+        for kw in ({}, {"flags_extra": pkg.FLAG_DETERMINISTIC}):
+            fl = flags | kw.get("flags_extra", 0)
+            r = pkg.Renderer(scene, max_depth=4, flags=fl)
+            for f in range(0, 12, 4):
+                r.render(4, seed=13, first_sample=f)
+            g = r.read_accum(); r.close()
+            assert g.shape == (h, w, 4) and np.all(g[..., 3] == 12) and np.isfinite(g).all(), (w, h, kw)
+        cpu, _, _ = orc.Oracle(scene, max_depth=4, flags=flags).render(12, seed=13)
+        assert _frac_beyond(g[..., :3] / 12, cpu[..., :3] / 12) <= 0.02, (w, h)
+
+
 def test_two_contexts_render_concurrently_from_two_threads(pkg):
     """Two contexts on one device, driven from two host threads at the same time (ctypes drops the GIL inside the calls; mcpt_cli --gpus
     uses one thread per context the same way): same films as when each renders alone."""
