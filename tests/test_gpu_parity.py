@@ -927,6 +927,32 @@ def test_extreme_film_shapes(pkg, orc):
         assert _frac_beyond(g[..., :3] / 12, cpu[..., :3] / 12) <= 0.02, (w, h)
 
 
+def test_degenerate_triangles_in_the_scene(pkg, orc):
+    """Zero-area triangles -- three collinear vertices, three identical vertices -- as ordinary geometry AND as a light (area 0: the
+    reference divides by it in Render.cpp:213-216 and in the emitter MIS, :153-160; whatever comes out is a NaN or inf that
+    Scene::set_Pixel scrubs or keeps).  The builders must accept them, the film must stay free of NaN, and GPU and oracle must agree."""
+    S = pkg.scenes
+    b = S.open_box(40, 32)
+    v = np.vstack([b.vertex, [[0.2, 0.5, 0.2], [0.4, 0.5, 0.4], [0.6, 0.5, 0.6], [0.7, 0.3, 0.7]]])      # three collinear points + one more
+    n0 = len(b.vertex)
+    light_mat = max(i for i, m in enumerate(b.materials) if any(m.radiance))
+    wall_mat = min(i for i, m in enumerate(b.materials) if not any(m.radiance))
+    def tri(a, bb, c, m): return [[a, 0, 0, m], [bb, 0, 0, m], [c, 0, 0, m]]
+    extra = np.array([tri(n0, n0 + 1, n0 + 2, wall_mat), tri(n0 + 3, n0 + 3, n0 + 3, wall_mat), tri(n0, n0 + 1, n0 + 2, light_mat)], np.int32)
+    scene = S.SceneData("degenerate", v, b.normal, b.texcoord, np.concatenate([b.face, extra]), b.materials, b.camera)
+    st, info, msg = pkg.check_scene(scene)
+    assert st == 0, msg
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    for fl in (flags, flags | pkg.FLAG_GPU_BVH_BUILD):
+        r = pkg.Renderer(scene, max_depth=4, flags=fl); r.render(16, seed=4); g = r.read_accum(); r.close()
+        assert np.all(g[..., 3] == 16) and not np.isnan(g).any(), fl
+    cpu, _, _ = orc.Oracle(scene, max_depth=4, flags=flags).render(16, seed=4)
+    assert not np.isnan(cpu).any()
+    both = np.isfinite(g[..., :3]).all(-1) & np.isfinite(cpu[..., :3]).all(-1)
+    assert np.array_equal(np.isfinite(g[..., :3]).all(-1), np.isfinite(cpu[..., :3]).all(-1))          # inf (kept by set_Pixel) in the same pixels
+    assert _frac_beyond(g[both][:, :3] / 16, cpu[both][:, :3] / 16) <= 0.02
+
+
 def test_two_contexts_render_concurrently_from_two_threads(pkg):
     """Two contexts on one device, driven from two host threads at the same time (ctypes drops the GIL inside the calls; mcpt_cli --gpus
     uses one thread per context the same way): same films as when each renders alone."""
