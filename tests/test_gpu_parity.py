@@ -953,6 +953,42 @@ def test_degenerate_triangles_in_the_scene(pkg, orc):
     assert _frac_beyond(g[both][:, :3] / 16, cpu[both][:, :3] / 16) <= 0.02
 
 
+def test_many_materials_and_many_lights_take_the_global_memory_tables(pkg, orc):
+    """The shade kernel stages up to 16 materials and 8 lights in LDS and reads larger tables from global memory.  A scene with 40
+    materials (diffuse, glossy, mirror, emissive) spread over the faces and ~30 light triangles takes the other path for both."""
+    S = pkg.scenes
+    b = S.cornell_box_small(48, 40)
+    rng = np.random.RandomState(23)
+    mats = []
+    for i in range(40):
+        kind = i % 5
+        kd = tuple(rng.uniform(0.1, 0.8, 3)); ks = (0.0, 0.0, 0.0); ns = 1.0; rad = (0.0, 0.0, 0.0)
+        if kind == 1: ks, ns = tuple(rng.uniform(0.1, 0.4, 3)), float(rng.choice([8.0, 60.0, 900.0]))
+        if kind == 2: ks, ns = (0.3, 0.3, 0.3), 10000.0
+        if kind == 3: rad = tuple(rng.uniform(1.0, 6.0, 3))
+        mats.append(S.Material("m%d" % i, kd, ks, ns, rad))
+    face = b.face.copy()
+    pick = rng.randint(0, 40, len(face))
+    pick[rng.rand(len(face)) < 0.9] //= 1                                 # (all faces re-assigned)
+    emissive = [i for i in range(40) if i % 5 == 3]
+    lights = rng.choice(len(face), 30, replace=False)
+    for f in range(len(face)):
+        m = int(pick[f])
+        if m % 5 == 3 and f not in lights: m = (m + 1) % 40               # keep the number of light triangles at ~30
+        face[f, :, 3] = m
+    for f in lights: face[f, :, 3] = int(rng.choice(emissive))
+    scene = S.SceneData("many-tables", b.vertex, b.normal, b.texcoord, face, mats, b.camera)
+    st, info, msg = pkg.check_scene(scene)
+    assert st == 0 and info.n_lights > 8, (msg, info.n_lights)
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    r = pkg.Renderer(scene, max_depth=5, flags=flags); r.render(16, seed=6); g = r.read_accum(); r.close()
+    cpu, _, _ = orc.Oracle(scene, max_depth=5, flags=flags).render(16, seed=6)
+    frac = _frac_beyond(g[..., :3] / 16, cpu[..., :3] / 16)
+    print("many tables: %d lights, pixels beyond tolerance %.3f %%" % (info.n_lights, 100 * frac))
+    assert np.all(g[..., 3] == 16) and frac <= 0.02
+    assert np.allclose((g[..., :3] / 16).mean((0, 1)), (cpu[..., :3] / 16).mean((0, 1)), rtol=2e-3)
+
+
 def test_two_contexts_render_concurrently_from_two_threads(pkg):
     """Two contexts on one device, driven from two host threads at the same time (ctypes drops the GIL inside the calls; mcpt_cli --gpus
     uses one thread per context the same way): same films as when each renders alone."""
