@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """Developer tool: where a shade wave's time goes (needs a library built with -DWF_SHADE_STATS; counters are re-purposed).
-usage: MCPT_LIB_PATH=build/libmcpt_hip_shstats.so python tools/shade_stats.py [spp] [lanes]"""
+usage: MCPT_LIB_PATH=build/libmcpt_hip_shstats.so python tools/shade_stats.py [spp] [cornell-box | bathroom:<detail>] [depth]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 os.environ["MCPT_TIME_KERNELS"] = "1"
-r = pkg.Renderer(pkg.scenes.cornell_box(800, 800), max_depth=8)
+name = sys.argv[2] if len(sys.argv) > 2 else "cornell-box"
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+scene = pkg.scenes.cornell_box(800, 800) if name == "cornell-box" else pkg.scenes.bathroom_stress(1920, 1080, detail=int(name.split(":")[1]))
+r = pkg.Renderer(scene, max_depth=depth)
 r.render(8, seed=1); r.sync(); r.reset_counters()
 r.render(spp, seed=2); r.sync(); c = r.counters()
 names = ["tables + slot records + class sort", "phase 1: hit record gather, emitter MIS", "phase 2: fp64 hit point + light sample",
