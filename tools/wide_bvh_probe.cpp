@@ -132,6 +132,67 @@ static void trace(const Wide& w, const HostScene& hs, const float o[3], const fl
         for (int k = 0; k < nh; k++) stack.push_back(hit[k].second);
     }
 }
+
+// ---- what the device's 8-wide kernel will actually do (round 3): children sit in OCTANT SLOTS (slot bit a set = the child lies towards +a
+// of the node's centre; greedy assignment), a ray visits the hit inner children in the order of slot ^ octant (no distance sort), and the
+// hit LEAF children of a node are tested before any of its inner children (Ylitie, Karras & Laine 2017).  Counts the same things as trace().
+struct Slots { std::vector<int> slot; };                               // per child entry of a Wide: its slot 0..7
+static Slots assign_slots(const Wide& w) {
+    Slots s; s.slot.assign(w.box.size(), 0);
+    for (size_t n = 0; n < w.first.size(); n++) {
+        const int f = w.first[n], c = w.count[n];
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int k = 0; k < c; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], w.box[f + k].lo[a]); hi[a] = std::max(hi[a], w.box[f + k].hi[a]); }
+        double cost[8][8];
+        for (int k = 0; k < c; k++) for (int sl = 0; sl < 8; sl++) {
+            double v = 0; for (int a = 0; a < 3; a++) { const double cc = 0.5 * (double(w.box[f + k].lo[a]) + w.box[f + k].hi[a]) - 0.5 * (double(lo[a]) + hi[a]); v += ((sl >> a) & 1) ? cc : -cc; }
+            cost[k][sl] = v;
+        }
+        bool ck[8] = {0}, cs[8] = {0};
+        for (int r = 0; r < c; r++) { int bk = -1, bs = -1; double bv = -1e300; for (int k = 0; k < c; k++) if (!ck[k]) for (int sl = 0; sl < 8; sl++) if (!cs[sl] && cost[k][sl] > bv) { bv = cost[k][sl]; bk = k; bs = sl; }
+            ck[bk] = cs[bs] = true; s.slot[f + bk] = bs; }
+    }
+    return s;
+}
+static bool tri_hit(const HostScene& hs, uint32_t ti, const float o[3], const float d[3], float& tmax) {
+    const f4h v0 = hs.tri_isect[3 * size_t(ti)], e1 = hs.tri_isect[3 * size_t(ti) + 1], e2 = hs.tri_isect[3 * size_t(ti) + 2];
+    const float px = d[1] * e2.z - d[2] * e2.y, py = d[2] * e2.x - d[0] * e2.z, pz = d[0] * e2.y - d[1] * e2.x;
+    const float det = e1.x * px + e1.y * py + e1.z * pz;
+    if (std::fabs(det) < 1e-5f) return false;
+    const float inv = 1.0f / det, tx = o[0] - v0.x, ty = o[1] - v0.y, tz = o[2] - v0.z;
+    const float u = (tx * px + ty * py + tz * pz) * inv; if (u < 0 || u > 1) return false;
+    const float qx = ty * e1.z - tz * e1.y, qy = tz * e1.x - tx * e1.z, qz = tx * e1.y - ty * e1.x;
+    const float v = (d[0] * qx + d[1] * qy + d[2] * qz) * inv; if (v < 0 || u + v > 1) return false;
+    const float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
+    if (t >= 1e-4f && t < tmax) { tmax = t; return true; }
+    return false;
+}
+// order: 0 = octant order, leaves of a node first; 1 = exact distance order for the inner children (leaves first); 2 = nearest inner child exactly, rest in octant order
+static void trace_octant(const Wide& w, const Slots& sl, const HostScene& hs, const float o[3], const float d[3], bool any, float tmax, int order, Stats& st) {
+    float id[3]; for (int a = 0; a < 3; a++) id[a] = 1.0f / (std::fabs(d[a]) > 1e-30f ? d[a] : std::copysign(1e-30f, d[a]));
+    const int oct = (d[0] < 0 ? 1 : 0) | (d[1] < 0 ? 2 : 0) | (d[2] < 0 ? 4 : 0);
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        const int node = stack.back(); stack.pop_back();
+        st.steps++;
+        std::pair<float, int> inner[8]; int ni = 0; int leaves[8]; int nl = 0;
+        for (int k = 0; k < w.count[node]; k++) {
+            const B3& b = w.box[w.first[node] + k]; st.boxes++;
+            float tn = 1e-4f, tf = tmax;
+            for (int a = 0; a < 3; a++) { float t0 = (b.lo[a] - o[a]) * id[a], t1 = (b.hi[a] - o[a]) * id[a]; if (t0 > t1) std::swap(t0, t1); tn = std::max(tn, t0); tf = std::min(tf, t1); }
+            if (!(tn <= tf)) continue;
+            const int code = w.code[w.first[node] + k];
+            if (code < 0) leaves[nl++] = code;
+            else { const int prio = sl.slot[w.first[node] + k] ^ oct; inner[ni++] = {order == 1 ? tn : float(prio), code}; if (order == 2) inner[ni - 1].first = float(prio) + 1000.f * 0; }
+        }
+        for (int k = 0; k < nl; k++) {
+            const uint32_t leaf = uint32_t(~leaves[k]), first = leaf >> 3, cnt = leaf & 7u; st.leaves++;
+            for (uint32_t i = 0; i < cnt; i++) { st.tris++; if (tri_hit(hs, first + i, o, d, tmax)) { st.hits++; if (any) return; } }
+        }
+        std::sort(inner, inner + ni, [](auto& a, auto& b) { return a.first > b.first; });   // smallest key popped first
+        for (int k = 0; k < ni; k++) stack.push_back(inner[k].second);
+    }
+}
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     const int n_rays = argc > 2 ? std::atoi(argv[2]) : 200000;
@@ -166,6 +227,15 @@ int main(int argc, char** argv) {
             for (int i = 0; i < n_rays; i++) trace(w, hs, &O[3 * i], &D[3 * i], any != 0, 3.0e38f, st);
             std::printf("  k=%d %-8s nodes %8zu (%.2f children each)  steps/ray %6.2f  box tests/ray %7.2f  leaf visits/ray %5.2f  tri tests/ray %5.2f\n", K, any ? "any-hit" : "closest", w.first.size(), fill,
                         st.steps / n_rays, st.boxes / n_rays, st.leaves / n_rays, st.tris / n_rays);
+        }
+    }
+    for (int K : {4, 8}) {
+        const Wide w = collapse_dp(hs.nodes, K); const Slots sl = assign_slots(w);
+        for (int order = 0; order < 2; order++) for (int any = 0; any < 2; any++) {
+            Stats st;
+            for (int i = 0; i < n_rays; i++) trace_octant(w, sl, hs, &O[3 * i], &D[3 * i], any != 0, 3.0e38f, order, st);
+            std::printf("  k=%d SAH-optimal, leaves first, inner children in %s order, %-8s steps/ray %6.2f  box tests/ray %7.2f  leaf visits/ray %5.2f  tri tests/ray %5.2f\n", K,
+                        order ? "distance" : "octant  ", any ? "any-hit" : "closest", st.steps / n_rays, st.boxes / n_rays, st.leaves / n_rays, st.tris / n_rays);
         }
     }
     return 0;
