@@ -74,9 +74,19 @@ struct DevCamera {                 // Render::cast_Ray's per-frame constants hoi
 //   f4[1] = u32 x4: qlo.x qlo.y qlo.z qhi.x   (byte k = child k, box = origin + q * 2^e, rounded outward)
 //   f4[2] = u32 x2: qhi.y qhi.z | 2 spare
 //   f4[3] = i32 x4: child codes (>= 0 inner node4 index, < 0 leaf ~(first << 3 | count); count 0 = empty)
+// nodes8: 80 B / node of the 8-wide compressed tree (breadth-first numbering; Ylitie, Karras & Laine 2017 re-laid for gfx950), five 16-B records:
+//   r[0] = origin x y z (fp32) | u32: scale_x << 16 | scale_y   (each scale = 2^e as a bfloat16, i.e. the top half of the fp32)
+//   r[1] = u32 child_base | u32 tri_base | u32 scale_z << 16 | u32 imask | p0 << 8 | p1 << 16
+//          slot s holds an inner child iff imask bit s: its record = child_base + popcount(imask & below(s));
+//          a leaf child of p0[s] + 2 p1[s] triangles otherwise: its first triangle = tri_base + popcount(p0 & below(s)) + 2 popcount(p1 & below(s))
+//   r[2] = x planes: u32 lo[slots 0-3] lo[4-7] hi[0-3] hi[4-7]   (byte k = slot; box = origin + q * scale, rounded outward;
+//   r[3] = y planes, r[4] = z planes                               an empty slot keeps lo = 255, hi = 0)
+//   Slots are OCTANT slots: bit a of s set = the child lies towards +a of the node's centre, so a ray meets the children roughly front to
+//   back in the order of s ^ (its direction octant).
 struct DevScene {
     const float4* nodes;
     const float4* nodes4;
+    const float4* nodes8;
     const float4* tri_isect;
     const float4* tri_shade;
     const double* tri_pos64;
@@ -87,7 +97,7 @@ struct DevScene {
     const double* light_pos64;     // 9 doubles / light: the fp64 corners of lights[i].tri again, contiguous (no lights[i].tri -> tri_pos64 chain)
     const float4* texels;
     DevCamera cam;
-    int32_t n_tris, n_lights, n_nodes, n_mats, n_nodes4;
+    int32_t n_tris, n_lights, n_nodes, n_mats, n_nodes4, n_nodes8;
 };
 
 struct RenderParams {

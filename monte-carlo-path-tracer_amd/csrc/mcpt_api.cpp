@@ -29,7 +29,7 @@ struct mcpt_ctx {
     int device = 0;
     mcpt_opts opts{};
     DevScene dev{};
-    DevBuf nodes, nodes4, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, light_pos64, texels, accum_own, counters;
+    DevBuf nodes, nodes4, nodes8, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, light_pos64, texels, accum_own, counters;
     float4* accum = nullptr;           // bound accumulator (own or external)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -83,7 +83,7 @@ hipError_t upload(DevBuf& b, const std::vector<T>& v) {
 void destroy_ctx(mcpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    c->nodes.free_(); c->nodes4.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_plane64.free_(); c->tri_face.free_();
+    c->nodes.free_(); c->nodes4.free_(); c->nodes8.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_plane64.free_(); c->tri_face.free_();
     c->mats.free_(); c->lights.free_(); c->light_pos64.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
     for (auto& L : c->lanes) {
         for (auto& b : L.pool_bufs) b.free_();
@@ -145,10 +145,11 @@ const char* mcpt_last_error(void) { return g_err.c_str(); }
 mcpt_status mcpt_check_scene(const mcpt_scene_desc* scene, mcpt_scene_info* out_info) {
     if (!scene) return fail(MCPT_ERR_INVALID_ARG, "mcpt_check_scene: null argument");
     HostScene hs; std::string err;
+    hs.bvh_width = env_u32("MCPT_BVH_WIDTH", 8) == 4 ? 4u : 8u;
     mcpt_status st = build_host_scene(scene, hs, err);
     if (st != MCPT_OK) return fail(st, err);
-    const std::string bad = validate_bvh4(hs);
-    if (!bad.empty()) return fail(MCPT_ERR_UNSUPPORTED, "internal: 4-wide BVH failed its self-check: " + bad);
+    const std::string bad = validate_wide_bvh(hs);
+    if (!bad.empty()) return fail(MCPT_ERR_UNSUPPORTED, "internal: wide BVH failed its self-check: " + bad);
     if (out_info) {
         std::memset(out_info, 0, sizeof *out_info);
         out_info->n_tris = uint32_t(hs.tri_face.size()); out_info->n_lights = uint32_t(hs.lights.size()); out_info->n_nodes = uint32_t(hs.nodes.size() / 4);
@@ -166,6 +167,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if (o.integrator > MCPT_INTEGRATOR_RECURSIVE_NEE) return fail(MCPT_ERR_INVALID_ARG, "unknown integrator");
 
     HostScene hs; std::string err;
+    hs.bvh_width = env_u32("MCPT_BVH_WIDTH", 8) == 4 ? 4u : 8u;          // developer knob: 4 = the round-2 4-wide tree and its kernel
     int ndev = 0;
     hipError_t e = hipSuccess;
     auto check_device = [&]() -> mcpt_status {
@@ -194,7 +196,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             return true;
         }, env_u32("MCPT_HOST_COLLAPSE", 0) ? Collapse4Fn(nullptr) : Collapse4Fn(gpu_collapse_bvh4));
         if (st != MCPT_OK) return fail(st, err);
-        if (env_u32("MCPT_VALIDATE_BVH", 0)) { const std::string bad = validate_bvh4(hs); if (!bad.empty()) return fail(MCPT_ERR_HIP, "device-built BVH failed validation: " + bad); }
+        if (env_u32("MCPT_VALIDATE_BVH", 0)) { const std::string bad = validate_wide_bvh(hs); if (!bad.empty()) return fail(MCPT_ERR_HIP, "device-built BVH failed validation: " + bad); }
     } else {
         st = build_host_scene(scene, hs, err);
         if (st != MCPT_OK) return fail(st, err);
@@ -211,6 +213,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = upload(c->nodes, hs.nodes)) != hipSuccess) return bail(e, "upload nodes");
     if ((e = upload(c->nodes4, hs.nodes4)) != hipSuccess) return bail(e, "upload nodes4");
+    if ((e = upload(c->nodes8, hs.nodes8)) != hipSuccess) return bail(e, "upload nodes8");
     if ((e = upload(c->tri_isect, hs.tri_isect)) != hipSuccess) return bail(e, "upload tri_isect");
     if ((e = upload(c->tri_shade, hs.tri_shade)) != hipSuccess) return bail(e, "upload tri_shade");
     if ((e = upload(c->tri_pos64, hs.tri_pos64)) != hipSuccess) return bail(e, "upload tri_pos64");
@@ -246,8 +249,8 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             // 485 / 478 / 466 / 474 ms at 160 / 192 / 224 / 256 blocks on the bench workload; r01's 132-register shade wanted 3/4) --
             // the rest of each CU's registers go to shade waves.  Once it spills out of L2
             // the trace kernel is the longer pole and wants every slot: 345 vs 366 ms at 48 MB, 838 vs 904 ms at 350 MB.
-            const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0));
-            const size_t traversal_bytes = hs.nodes4.size() * sizeof(f4h) + hs.tri_isect.size() * sizeof(f4h);
+            const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0, hs.bvh_width));
+            const size_t traversal_bytes = (hs.nodes4.size() + hs.nodes8.size()) * sizeof(f4h) + hs.tri_isect.size() * sizeof(f4h);
             const bool cache_resident = traversal_bytes <= (size_t(16) << 20);
             c->trace_grid = (n_lanes > 1 && cache_resident) ? std::max(1u, uint32_t(c->n_cus) * 7u / 8u) : uint32_t(c->n_cus) * per_cu;
             c->trace_grid = std::min(env_u32("MCPT_WF_GRID", c->trace_grid), uint32_t(c->n_cus) * per_cu);
@@ -274,7 +277,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
                 for (auto& ev : L.chk_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
                 if ((e = hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
                 if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-                if ((e = L.ovf_buf.alloc(size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_levels(hs.bvh4_depth) * sizeof(int))) != hipSuccess)
+                if ((e = L.ovf_buf.alloc(size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_bytes_per_lane(hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth, hs.bvh_width))) != hipSuccess)
                     return bail(e, "alloc stack overflow area");
             }
         }
@@ -283,7 +286,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     c->accum = static_cast<float4*>(c->accum_own.p);
 
     DevScene& d = c->dev;
-    d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes4 = static_cast<const float4*>(c->nodes4.p); d.n_nodes4 = int32_t(hs.nodes4.size() / 4); d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
+    d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes4 = static_cast<const float4*>(c->nodes4.p); d.n_nodes4 = int32_t(hs.nodes4.size() / 4); d.nodes8 = static_cast<const float4*>(c->nodes8.p); d.n_nodes8 = int32_t(hs.nodes8.size() / 5); d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
     d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p); d.tri_plane64 = static_cast<const double*>(c->tri_plane64.p);
     d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
     d.lights = static_cast<const DevLight*>(c->lights.p); d.light_pos64 = static_cast<const double*>(c->light_pos64.p); d.texels = static_cast<const float4*>(c->texels.p);
@@ -294,7 +297,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     mcpt_scene_info& in = c->info;
     in.n_tris = uint32_t(d.n_tris); in.n_lights = uint32_t(d.n_lights); in.n_nodes = uint32_t(d.n_nodes);
     in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
-    in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes + c->mats.bytes +
+    in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes + c->mats.bytes +
                       c->lights.bytes + c->light_pos64.bytes + c->texels.bytes + accum_bytes;
     for (auto& L : c->lanes) for (auto& b : L.pool_bufs) in.device_bytes += b.bytes;
     in.bvh_build_ms = hs.bvh_build_ms;

@@ -213,14 +213,13 @@ inline float from_u32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 // 3.5 instead of 2.9 of 4 slots filled, ~20 % fewer nodes, -3 % / -8 % closest-hit / any-hit steps per ray on S-cornell
 // (tools/wide_bvh_probe.sh) -- and no faster on the device, see build_bvh4.
 struct CollapsePlan {
-    static constexpr int K = 4;
+    int K = 4;
     std::vector<unsigned char> split;                                   // [n * (K + 1) + i]
     unsigned char at(int n, int i) const { return split[size_t(n) * (K + 1) + i]; }
 };
-CollapsePlan plan_collapse(const std::vector<f4h>& n2) {
-    constexpr int K = CollapsePlan::K;
+CollapsePlan plan_collapse(const std::vector<f4h>& n2, int K) {
     const int N = int(n2.size() / 4);
-    CollapsePlan p; p.split.assign(size_t(N) * (K + 1), 0);
+    CollapsePlan p; p.K = K; p.split.assign(size_t(N) * (K + 1), 0);
     std::vector<int> order; order.reserve(N);                           // parents before children
     { std::vector<int> st{0}; while (!st.empty()) { const int n = st.back(); st.pop_back(); order.push_back(n); for (int k = 0; k < 2; k++) { const int c = child2(n2, n, k); if (c >= 0) st.push_back(c); } } }
     auto own_area = [&](int n) { Box3f a = box2(n2, n, 0); const Box3f b = box2(n2, n, 1); for (int x = 0; x < 3; x++) { a.lo[x] = std::min(a.lo[x], b.lo[x]); a.hi[x] = std::max(a.hi[x], b.hi[x]); } return area3(a); };
@@ -240,19 +239,34 @@ CollapsePlan plan_collapse(const std::vector<f4h>& n2) {
     }
     return p;
 }
+// The children a K-wide node adopts under the plan: the roots of the forest below binary node `node2` that fills its K slots.
+struct Kid { int code; Box3f box; };
+void planned_kids(const std::vector<f4h>& n2, const CollapsePlan& plan, int node2, std::vector<Kid>& kids) {
+    struct Item { int parent, k, slots; };
+    std::vector<Item> todo;
+    { const int a = plan.at(node2, 1); todo.push_back({node2, 1, plan.K - a}); todo.push_back({node2, 0, a}); }
+    while (!todo.empty()) {
+        const Item it = todo.back(); todo.pop_back();
+        const int c = child2(n2, it.parent, it.k);
+        int i = it.slots;
+        if (c >= 0) while (i > 1 && plan.at(c, i) == 0) i--;
+        if (c < 0 || i == 1) { kids.push_back({c, box2(n2, it.parent, it.k)}); continue; }
+        const int a = plan.at(c, i);
+        todo.push_back({c, 1, i - a}); todo.push_back({c, 0, a});
+    }
+}
 
 void build_bvh4(HostScene& out) {
     const std::vector<f4h>& n2 = out.nodes;
     std::vector<f4h>& n4 = out.nodes4;
     n4.clear();
-    struct Kid { int code; Box3f box; };
     struct Work { int node2, slot4; uint32_t depth; };
     // Default: adopt the children of the largest inner child until the node is full.  MCPT_COLLAPSE=sah (developer knob) follows the
     // SAH-optimal plan instead: measured on MI355X -1 % on S-cornell (fuller nodes = more valid boxes to test per visit: 31.8 vs 30.7 box
     // tests per ray, though 3 - 8 % fewer visits), +-0 on S-veach and S-bath 0.59 M, +1 % on S-bath 4 M (20 % fewer node bytes).
     const char* mode = std::getenv("MCPT_COLLAPSE");
     const bool optimal = mode && std::string(mode) == "sah";
-    const CollapsePlan plan = optimal ? plan_collapse(n2) : CollapsePlan();
+    const CollapsePlan plan = optimal ? plan_collapse(n2, 4) : CollapsePlan();
     // breadth-first emission => the first MCPT_TOP_NODES records are the top levels (LDS-resident in the trace kernel)
     std::vector<Work> queue{{0, 0, 1}};
     n4.resize(4);
@@ -261,20 +275,8 @@ void build_bvh4(HostScene& out) {
         const Work w = queue[qh];
         out.bvh4_depth = std::max(out.bvh4_depth, w.depth);
         std::vector<Kid> kids;
-        if (optimal) {                                                  // follow the plan: the roots of the forest below w.node2 that fills 4 slots
-            struct Item { int parent, k, slots; };
-            std::vector<Item> todo;
-            { const int a = plan.at(w.node2, 1); todo.push_back({w.node2, 1, 4 - a}); todo.push_back({w.node2, 0, a}); }
-            while (!todo.empty()) {
-                const Item it = todo.back(); todo.pop_back();
-                const int c = child2(n2, it.parent, it.k);
-                int i = it.slots;
-                if (c >= 0) while (i > 1 && plan.at(c, i) == 0) i--;
-                if (c < 0 || i == 1) { kids.push_back({c, box2(n2, it.parent, it.k)}); continue; }
-                const int a = plan.at(c, i);
-                todo.push_back({c, 1, i - a}); todo.push_back({c, 0, a});
-            }
-        } else {
+        if (optimal) planned_kids(n2, plan, w.node2, kids);             // follow the plan: the roots of the forest below w.node2 that fills 4 slots
+        else {
             for (int k = 0; k < 2; k++) kids.push_back({child2(n2, w.node2, k), box2(n2, w.node2, k)});
             while (kids.size() < 4) {
                 int best = -1; double ba = -1.0;
@@ -329,6 +331,112 @@ void build_bvh4(HostScene& out) {
     }
 }
 
+
+// ---- 8-wide compressed BVH for the wavefront trace kernel (device_scene.h: nodes8) --------------------------------------------
+// Ylitie, Karras & Laine 2017 ("Efficient incoherent ray traversal on GPUs through compressed wide BVHs"), laid out for gfx950.
+// The binary SAH tree is collapsed SAH-optimally to 8 children per node (plan_collapse; binary leaves stay as the builder made them).
+// A node's children sit in OCTANT SLOTS: slot bit a set = the child lies towards +a of the node's centre (greedy assignment), so a ray
+// with direction octant `oct` meets the children roughly front to back in the order of slot ^ oct -- the kernel needs no distance sort and
+// a whole node's pending children are ONE stack entry (child base + hit mask).  Inner children are numbered consecutively in slot order
+// (child = child_base + popcount(imask & below(slot))), and the triangles of a node's leaf children are consecutive in slot order
+// (triangle = tri_base + sum of the counts below the slot): the leaf order of every triangle stream is therefore defined HERE, and
+// `order` plus the leaf codes of the binary tree are rewritten to it.  One node = 80 B = five 16-B records, see device_scene.h.
+inline uint32_t bf16_pow2(int e) { return uint32_t(e + 127) << 7; }     // 2^e as a bfloat16 (the top half of the fp32)
+void build_bvh8(HostScene& out, std::vector<int>& order) {
+    static_assert(MCPT_LEAF_MAX <= 3, "a leaf child's triangle count is two bits in the 8-wide node");
+    std::vector<f4h>& n2 = out.nodes;
+    std::vector<f4h>& n8 = out.nodes8;
+    const CollapsePlan plan = plan_collapse(n2, 8);
+    struct Work { int node2, rec; uint32_t depth; };
+    std::vector<Work> queue{{0, 0, 1}};
+    n8.assign(5, f4h{0.f, 0.f, 0.f, 0.f});
+    out.bvh8_depth = 1;
+    std::vector<int> new_order; new_order.reserve(order.size());
+    std::vector<int> new_first(order.size() + 1, -1);                   // old first position of a leaf -> its new one
+    std::vector<Kid> kids;
+    for (size_t qh = 0; qh < queue.size(); qh++) {
+        const Work w = queue[qh];
+        out.bvh8_depth = std::max(out.bvh8_depth, w.depth);
+        kids.clear();
+        planned_kids(n2, plan, w.node2, kids);
+        for (size_t i = 0; i < kids.size();) { if (kids[i].code < 0 && ((uint32_t(~kids[i].code)) & 7u) == 0) kids.erase(kids.begin() + i); else i++; }   // (the empty second child of a one-leaf scene)
+        const int nk = int(kids.size());
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        for (const Kid& k : kids) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], k.box.lo[a]); hi[a] = std::max(hi[a], k.box.hi[a]); }
+        if (kids.empty()) { for (int a = 0; a < 3; a++) lo[a] = hi[a] = 0.f; }
+        // octant slots: greedily give the (child, slot) pair with the largest projection of the child's offset from the node centre on the slot's diagonal
+        int slot_of[8]; int kid_in[8]; for (int sl = 0; sl < 8; sl++) kid_in[sl] = -1;
+        {
+            double cost[8][8]; bool ck[8] = {false}, cs[8] = {false};
+            for (int k = 0; k < nk; k++) for (int sl = 0; sl < 8; sl++) {
+                double v = 0;
+                for (int a = 0; a < 3; a++) { const double cc = 0.5 * (double(kids[k].box.lo[a]) + kids[k].box.hi[a]) - 0.5 * (double(lo[a]) + hi[a]); v += ((sl >> a) & 1) ? cc : -cc; }
+                cost[k][sl] = v;
+            }
+            for (int r = 0; r < nk; r++) {
+                int bk = -1, bs = -1; double bv = -INFINITY;
+                for (int k = 0; k < nk; k++) if (!ck[k]) for (int sl = 0; sl < 8; sl++) if (!cs[sl] && (bk < 0 || cost[k][sl] > bv)) { bv = cost[k][sl]; bk = k; bs = sl; }
+                ck[bk] = cs[bs] = true; slot_of[bk] = bs; kid_in[bs] = bk;
+            }
+        }
+        int ebits[3]; double scale[3];
+        for (int a = 0; a < 3; a++) {
+            const double ext = double(hi[a]) - double(lo[a]);
+            int e = ext > 0 ? int(std::ceil(std::log2(ext / 255.0))) : -100;
+            while (ext > 0 && std::ldexp(255.0, e) < ext) e++;                       // guard log2 rounding
+            e = std::max(-126, std::min(127, e));
+            ebits[a] = e; scale[a] = std::ldexp(1.0, e);
+        }
+        // empty slots keep an inverted box (lo 255, hi 0): no ray interval survives it
+        uint32_t q[3][2][2];                                                         // [axis][lo / hi][slots 0-3 / 4-7]
+        for (int a = 0; a < 3; a++) { q[a][0][0] = q[a][0][1] = 0xffffffffu; q[a][1][0] = q[a][1][1] = 0u; }
+        uint32_t imask = 0, p0 = 0, p1 = 0;
+        const uint32_t child_base = uint32_t(n8.size() / 5), tri_base = uint32_t(new_order.size());
+        for (int sl = 0; sl < 8; sl++) {
+            const int k = kid_in[sl]; if (k < 0) continue;
+            for (int a = 0; a < 3; a++) {
+                double ql = std::floor((double(kids[k].box.lo[a]) - double(lo[a])) / scale[a]);
+                double qh = std::ceil((double(kids[k].box.hi[a]) - double(lo[a])) / scale[a]);
+                while (ql > 0 && float(double(lo[a]) + ql * scale[a]) > kids[k].box.lo[a]) ql -= 1;      // the fp32 reconstruction must still enclose the child box
+                while (qh < 255 && float(double(lo[a]) + qh * scale[a]) < kids[k].box.hi[a]) qh += 1;
+                ql = std::min(255.0, std::max(0.0, ql)); qh = std::min(255.0, std::max(0.0, qh));
+                const int h = sl >> 2, sh = 8 * (sl & 3);
+                q[a][0][h] = (q[a][0][h] & ~(0xffu << sh)) | (uint32_t(ql) << sh);
+                q[a][1][h] = (q[a][1][h] & ~(0xffu << sh)) | (uint32_t(qh) << sh);
+            }
+            if (kids[k].code >= 0) {                                                 // inner child: its record follows its lower-slot siblings
+                imask |= 1u << sl;
+                const int rec = int(n8.size() / 5);
+                n8.resize(n8.size() + 5, f4h{0.f, 0.f, 0.f, 0.f});
+                queue.push_back({kids[k].code, rec, w.depth + 1});
+            } else {                                                                 // leaf child: its triangles follow those of its lower-slot siblings
+                const uint32_t leaf = uint32_t(~kids[k].code), first = leaf >> 3, cnt = leaf & 7u;
+                p0 |= (cnt & 1u) << sl; p1 |= ((cnt >> 1) & 1u) << sl;
+                new_first[first] = int(new_order.size());
+                for (uint32_t i = 0; i < cnt; i++) new_order.push_back(order[first + i]);
+            }
+        }
+        f4h* r = &n8[5 * size_t(w.rec)];
+        r[0] = {lo[0], lo[1], lo[2], from_u32((bf16_pow2(ebits[0]) << 16) | bf16_pow2(ebits[1]))};
+        r[1] = {from_u32(child_base), from_u32(tri_base), from_u32(bf16_pow2(ebits[2]) << 16), from_u32(imask | (p0 << 8) | (p1 << 16))};
+        r[2] = {from_u32(q[0][0][0]), from_u32(q[0][0][1]), from_u32(q[0][1][0]), from_u32(q[0][1][1])};   // x: lo 0-3, lo 4-7, hi 0-3, hi 4-7
+        r[3] = {from_u32(q[1][0][0]), from_u32(q[1][0][1]), from_u32(q[1][1][0]), from_u32(q[1][1][1])};   // y
+        r[4] = {from_u32(q[2][0][0]), from_u32(q[2][0][1]), from_u32(q[2][1][0]), from_u32(q[2][1][1])};   // z
+    }
+    // the new leaf order: every triangle stream and the binary tree's leaf codes follow it
+    const size_t nb = n2.size() / 4;
+    for (size_t n = 0; n < nb; n++) for (int k = 0; k < 2; k++) {
+        const int c = child2(n2, int(n), k);
+        if (c >= 0) continue;
+        const uint32_t leaf = uint32_t(~c), first = leaf >> 3, cnt = leaf & 7u;
+        if (cnt == 0) continue;
+        const int code = leaf_code(uint32_t(new_first[first]), cnt);
+        (k == 0 ? n2[4 * n + 3].x : n2[4 * n + 3].y) = as_float(code);
+    }
+    order.swap(new_order);
+}
+
 }  // namespace
 
 // Self-check used by mcpt_check_scene: walk the 4-wide tree exactly as the kernel dequantises it (fp32: origin + q * 2^e) and verify
@@ -362,6 +470,58 @@ std::string validate_bvh4(const HostScene& hs) {
             }
             if (codes[k] >= 0) { stack.push_back(ch); continue; }
             const uint32_t leaf = uint32_t(~codes[k]), first = leaf >> 3, cnt = leaf & 7u;
+            if (size_t(first) + cnt > nt) return "leaf range out of bounds";
+            for (uint32_t t = first; t < first + cnt; t++) {
+                if (seen[t]++) return "triangle referenced twice";
+                const f4h v0 = hs.tri_isect[3 * size_t(t)], e1 = hs.tri_isect[3 * size_t(t) + 1], e2 = hs.tri_isect[3 * size_t(t) + 2];
+                const float P[3][3] = {{v0.x, v0.y, v0.z}, {v0.x + e1.x, v0.y + e1.y, v0.z + e1.z}, {v0.x + e2.x, v0.y + e2.y, v0.z + e2.z}};
+                for (int c = 0; c < 3; c++) for (int a = 0; a < 3; a++)
+                    if (!(P[c][a] >= ch.lo[a] && P[c][a] <= ch.hi[a])) return "triangle " + std::to_string(t) + " sticks out of a quantised box on its path";
+            }
+        }
+    }
+    for (size_t t = 0; t < nt; t++) if (!seen[t]) return "triangle " + std::to_string(t) + " not reachable";
+    return "";
+}
+
+// The same soundness walk for the 8-wide tree: boxes dequantised the way wf_trace_kernel does, children and triangles located the way it
+// locates them (child_base + rank among the inner slots; tri_base + the counts of the lower leaf slots).
+std::string validate_bvh8(const HostScene& hs) {
+    const size_t n8 = hs.nodes8.size() / 5, nt = hs.tri_face.size();
+    if (n8 == 0) return "empty nodes8";
+    std::vector<uint8_t> seen(nt, 0);
+    struct Item { uint32_t node; float lo[3], hi[3]; };
+    std::vector<Item> stack;
+    Item root; root.node = 0; for (int a = 0; a < 3; a++) { root.lo[a] = -INFINITY; root.hi[a] = INFINITY; }
+    stack.push_back(root);
+    size_t visited = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        if (size_t(it.node) >= n8) return "child link out of range";
+        if (++visited > n8) return "cycle in nodes8";
+        const f4h* r = &hs.nodes8[5 * size_t(it.node)];
+        const uint32_t sxy = as_u32(r[0].w), szw = as_u32(r[1].z), masks = as_u32(r[1].w), child_base = as_u32(r[1].x), tri_base = as_u32(r[1].y);
+        const float sc[3] = {from_u32(sxy & 0xffff0000u), from_u32(sxy << 16), from_u32(szw & 0xffff0000u)};
+        const float org[3] = {r[0].x, r[0].y, r[0].z};
+        const uint32_t imask = masks & 0xffu, p0 = (masks >> 8) & 0xffu, p1 = (masks >> 16) & 0xffu;
+        if (imask & (p0 | p1)) return "a slot is both inner and leaf";
+        const f4h* Q = r + 2;
+        for (int sl = 0; sl < 8; sl++) {
+            const bool inner = (imask >> sl) & 1u; const uint32_t cnt = ((p0 >> sl) & 1u) + 2u * ((p1 >> sl) & 1u);
+            const uint32_t below = (1u << sl) - 1u, sh = 8u * (sl & 3);
+            Item ch;
+            bool inverted = false;
+            for (int a = 0; a < 3; a++) {
+                const uint32_t wl = as_u32(sl < 4 ? Q[a].x : Q[a].y), wh = as_u32(sl < 4 ? Q[a].z : Q[a].w);
+                const float qlo = float((wl >> sh) & 0xffu), qhi = float((wh >> sh) & 0xffu);
+                if (qlo > qhi) inverted = true;
+                const float lo = org[a] + qlo * sc[a], hi = org[a] + qhi * sc[a];
+                ch.lo[a] = std::max(it.lo[a], lo); ch.hi[a] = std::min(it.hi[a], hi);
+            }
+            if (!inner && cnt == 0) { if (!inverted) return "an empty slot has a box a ray could enter"; continue; }
+            if (inverted) return "an occupied slot has an inverted box";
+            if (inner) { ch.node = child_base + uint32_t(__builtin_popcount(imask & below)); stack.push_back(ch); continue; }
+            const uint32_t first = tri_base + uint32_t(__builtin_popcount(p0 & below)) + 2u * uint32_t(__builtin_popcount(p1 & below));
             if (size_t(first) + cnt > nt) return "leaf range out of bounds";
             for (uint32_t t = first; t < first + cnt; t++) {
                 if (seen[t]++) return "triangle referenced twice";
@@ -487,10 +647,13 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     out.binary_ok = out.bvh_depth <= uint32_t(MCPT_STACK_DEPTH - 1);
     if (!out.binary_ok && !out.allow_deep_binary) { err = "BVH depth exceeds traversal stack"; return MCPT_ERR_BVH_DEPTH; }
-    if (custom_collapse) { if (!custom_collapse(out.nodes, out.nodes4, out.bvh4_depth, err)) return MCPT_ERR_HIP; }
+    out.nodes4.clear(); out.nodes8.clear(); out.bvh4_depth = out.bvh8_depth = 0;
+    if (out.bvh_width == 8) build_bvh8(out, order);                       // (defines the leaf order: `order` and the binary leaf codes are rewritten)
+    else if (custom_collapse) { if (!custom_collapse(out.nodes, out.nodes4, out.bvh4_depth, err)) return MCPT_ERR_HIP; }
     else build_bvh4(out);
-    if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] 4-wide collapse done at %.0f ms (%zu nodes4, depth %u)\n",
-                                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), out.nodes4.size() / 4, out.bvh4_depth);
+    if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] %u-wide collapse done at %.0f ms (%zu nodes, depth %u)\n", out.bvh_width,
+                                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                                                 out.bvh_width == 8 ? out.nodes8.size() / 5 : out.nodes4.size() / 4, out.bvh_width == 8 ? out.bvh8_depth : out.bvh4_depth);
     std::vector<int> pos_of_face(nf);
     for (uint32_t i = 0; i < nf; i++) pos_of_face[order[i]] = int(i);
 

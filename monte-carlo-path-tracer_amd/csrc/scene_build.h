@@ -12,7 +12,8 @@ struct f4h { float x, y, z, w; };   // host mirror of float4 (16 B)
 
 struct HostScene {
     std::vector<f4h> nodes;          // 4 per inner node (binary tree: megakernel + probes)
-    std::vector<f4h> nodes4;         // 4 per node of the 4-wide quantised tree (wavefront trace kernel)
+    std::vector<f4h> nodes4;         // 4 per node of the 4-wide quantised tree (wavefront trace kernel, bvh_width == 4)
+    std::vector<f4h> nodes8;         // 5 per node of the 8-wide compressed tree (wavefront trace kernel, bvh_width == 8: the default)
     std::vector<f4h> tri_isect;      // 3 per triangle (leaf order)
     std::vector<f4h> tri_shade;      // 4 per triangle
     std::vector<double> tri_pos64;   // 9 per triangle
@@ -23,7 +24,8 @@ struct HostScene {
     std::vector<double> light_pos64; // 9 per light
     std::vector<f4h> texels;
     DevCamera cam;
-    uint32_t bvh_depth = 0, max_leaf = 0, bvh4_depth = 0;
+    uint32_t bvh_depth = 0, max_leaf = 0, bvh4_depth = 0, bvh8_depth = 0;
+    uint32_t bvh_width = 8;          // in: which wide tree the wavefront trace kernel will walk (4 = the round-2 tree, a developer knob)
     bool allow_deep_binary = false;  // in: the caller never traverses `nodes` (wavefront pipeline only) -> a device tree deeper than MCPT_STACK_DEPTH is fine
     bool binary_ok = true;           // out: `nodes` fits the binary-tree kernels' stack
     double bvh_build_ms = 0.0;
@@ -44,3 +46,5 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
 
 // Host-side soundness check of the quantised 4-wide tree (empty string = sound); run by mcpt_check_scene.
 std::string validate_bvh4(const HostScene& hs);
+std::string validate_bvh8(const HostScene& hs);
+inline std::string validate_wide_bvh(const HostScene& hs) { return hs.bvh_width == 8 ? validate_bvh8(hs) : validate_bvh4(hs); }

@@ -842,6 +842,326 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #undef WF_POP_NODE
 #undef WF_NODE_WAIT
 #endif
+#undef WF_TICK
+// ====================================================================================================== trace, 8-wide tree
+// BVH_node::hit / has_hit (BVH.cpp:95-136), AABB::Intersection (AABB.cpp:25-36), Triangle::hit / isIntersect (Triangle.cpp:48-106) for the
+// whole ray list of one iteration, over the 8-wide compressed tree (device_scene.h: nodes8; Ylitie, Karras & Laine 2017, re-laid for
+// gfx950).  Same three-block wave scheduler, ray list and acceptance rules as wf_trace_kernel above; what differs is the unit of traversal:
+//   * one inner step = one 80-B record = EIGHT child boxes (8-bit offsets in the node's frame, two FMAs per plane after a v_cvt_f32_ubyteN),
+//     the result an 8-bit hit mask -- no entry distances, no sorting network: the children sit in octant slots (scene_build.cpp), a ray
+//     visits them in the order of slot ^ octant, which is front to back up to ties;
+//   * the traversal state is a GROUP: G = {child base, imask << 8 | pending hit mask (octant-permuted: lowest bit first)} names all pending
+//     inner children of one node in 8 B, T = {triangle base, leaf hits << 24 | count planes << 8} all its pending leaf children.  One stack
+//     entry per node instead of one per child: the stack is an 8-B-per-level LDS array, WF8_LDS_STACK deep (deeper levels spill to a global
+//     overflow area), with at most two pushes and one pop per step;
+//   * speculative traversal as before: a lane parks the leaf group of a node in T and goes on with the node's inner children; the leaf group
+//     of a later node found while T is still occupied is pushed UNDER that node's inner group and parked when it is popped.
+#ifndef WF8_LDS_STACK
+#define WF8_LDS_STACK 6
+#endif
+#ifndef MCPT_TOP_NODES8
+#define MCPT_TOP_NODES8 192         // records numbered breadth-first by the builder; 192 x 80 B = 15 KB of LDS
+#endif
+template <bool COUNT>
+__global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
+                                                                   int* __restrict__ stack_overflow) {
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ v2u s_stack[WF8_LDS_STACK * WF_TRACE_BLOCK];
+    __shared__ float4 s_top[5 * MCPT_TOP_NODES8];                      // [record][node]
+    typedef __attribute__((address_space(3))) v2u lds_u2;              // explicit address spaces: see wf_trace_kernel
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    typedef __attribute__((address_space(1))) v2u glb_u2;
+    typedef __attribute__((address_space(1))) const v4f glb_cf4;
+    lds_u2* stk = (lds_u2*)s_stack + threadIdx.x;
+    lds_f4* top = (lds_f4*)s_top;
+    const uint32_t ovf_stride = gridDim.x * WF_TRACE_BLOCK;
+#define OVF8(LEVEL) (((glb_u2*)stack_overflow)[(uint32_t)(LEVEL) * ovf_stride + (blockIdx.x * WF_TRACE_BLOCK + threadIdx.x)])
+    glb_cf4* gnodes = (glb_cf4*)sc.nodes8;
+    const int n_top = sc.n_nodes8 < MCPT_TOP_NODES8 ? sc.n_nodes8 : MCPT_TOP_NODES8;
+    for (int i = threadIdx.x; i < 5 * n_top; i += WF_TRACE_BLOCK) s_top[(i % 5) * MCPT_TOP_NODES8 + (i / 5)] = sc.nodes8[i];
+    __syncthreads();
+#ifdef WF_SCHED_STATS
+    const unsigned long long t_start = wall_clock64();
+#endif
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t P = pool.P;
+    // the ray list and its chunks: exactly as in wf_trace_kernel
+    const uint32_t n_ext_chunks = P / WF_SHADE_BLOCK;
+    const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
+    const uint32_t sub_sh = 2 * n_ext_chunks < n_waves ? 2u : 0u;
+    const uint32_t n_chunks = (2 * n_ext_chunks) << sub_sh;
+    uint32_t* head = &ctl->trace_head[it & 3];
+    uint32_t w_next = 0, w_end = 0, q_base = 0;
+    bool chunk_shadow = false, exhausted = false;
+    auto take_chunk = [&](uint32_t c) {
+        const uint32_t cc = c >> sub_sh, part = c & ((1u << sub_sh) - 1u), span = (uint32_t)WF_SHADE_BLOCK >> sub_sh;
+        const bool none = c >= n_chunks, ext = cc < n_ext_chunks, shadow = !none && !ext;
+        const uint32_t b = shadow ? cc - n_ext_chunks : 0u;
+        uint32_t cnt = ext ? (uint32_t)WF_SHADE_BLOCK : 0u;
+        if (shadow) cnt = wave_first(ld_s(&pool.shadow_count[b]));
+        const uint32_t lo = min(part * span, cnt), hi = min(lo + span, cnt), base = ext ? cc * WF_SHADE_BLOCK : 0u;
+        exhausted = exhausted || none;
+        chunk_shadow = shadow;
+        q_base = b * WF_SHADE_BLOCK;
+        w_next = base + lo;
+        w_end = base + hi;
+    };
+    const bool short_list = n_chunks < n_waves * WF_CHUNK_BATCH;
+    const uint32_t batch = short_list ? max(1u, n_chunks / n_waves) : (uint32_t)WF_CHUNK_BATCH;
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_id = short_list ? wave_in_block * gridDim.x + blockIdx.x : blockIdx.x * (WF_TRACE_BLOCK / 64) + wave_in_block;
+    uint32_t c_next = wave_id * batch, c_end = c_next + batch;
+    take_chunk(c_next++);
+
+    bool have = false, any = false, blocked = false;
+    uint32_t slot = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+    float idx = 0, idy = 0, idz = 0, tmax = 0;
+    // cur = the group on top of the lane's stack, held in registers: .y & 0xff != 0 -> inner group G; .y != 0 otherwise -> a leaf group
+    // waiting for the parking place; .y == 0 -> bottom of the stack (the ray is finished once T is empty too).  T = the parked leaf group.
+    uint32_t cur_x = 0, cur_y = 0, t_x = 0, t_y = 0, oct = 0;
+    int sp = 1;
+    int htri = -1; float hu = 0, hv = 0;
+    uint32_t n_box = 0, n_tri = 0, n_spill = 0;
+#ifdef WF_SCHED_STATS
+    uint32_t x_inner = 0, x_leaf = 0, x_refill = 0, l_refill = 0;
+    unsigned long long t_inner = 0, t_leaf = 0, t_refill = 0, t_mark = __builtin_amdgcn_s_memtime();
+#define WF_TICK(acc) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc += t_now - t_mark; t_mark = t_now; }
+#else
+#define WF_TICK(acc)
+#endif
+#define WF8_POP() { sp--; v2u e_; if (sp < WF8_LDS_STACK) e_ = stk[sp * WF_TRACE_BLOCK]; else e_ = OVF8(sp - WF8_LDS_STACK); cur_x = e_.x; cur_y = e_.y; }
+    // a leaf group on top of the stack moves to the parking place as soon as that is free, and the lane goes on with what lies below
+#define WF8_PARK() if (t_y == 0u && cur_y != 0u && (cur_y & 0xffu) == 0u) { t_x = cur_x; t_y = cur_y; WF8_POP() }
+    const bool speculate = tune.pend_cap != 0u;      // MCPT_WF_PEND=0 (developer knob): a lane with a parked leaf group waits for the leaf block
+    const bool greedy = tune.policy == 1;
+
+    uint32_t watchdog = 0;
+    for (;;) {
+        if (++watchdog > (1u << 24)) { if (lane == 0) ctl->pad[0] = 1u; break; }
+        const bool at_leaf = have && t_y != 0u;                                          // carries a parked leaf group
+        const bool at_inner = have && (cur_y & 0xffu) != 0u && (speculate || !at_leaf);   // can take an inner step
+        const int n_inner = __popcll(__ballot(at_inner)), n_pend = __popcll(__ballot(at_leaf));
+        const int n_leaf = __popcll(__ballot(at_leaf && !at_inner));                     // ... and cannot go on without the leaf block
+        const int n_idle = 64 - n_inner - n_leaf;
+
+        const int most = n_inner > n_leaf ? n_inner : n_leaf;
+        if ((n_inner + n_leaf == 0) || (!exhausted && (greedy ? n_idle >= most : n_idle >= (int)tune.refill_at))) {
+            // ------------------------------------------------------------------ refill block
+#ifdef WF_SCHED_STATS
+            x_refill++; l_refill += (uint32_t)n_idle;
+#endif
+            if (have && cur_y == 0u && t_y == 0u) {                      // finished: write the result back
+                if (any) {
+                    if (blocked) st_s(reinterpret_cast<uint32_t*>(&pool.nee[slot]) + 3, 1u);
+                } else {
+                    st_s(&pool.hit[slot], make_float4(__int_as_float(htri), hu, hv, tmax));
+                }
+                have = false;
+            }
+            if (!exhausted) {
+                const uint64_t m_idle = __ballot(!have);
+                const uint32_t rank = lane_rank(m_idle);
+                uint32_t remaining = (uint32_t)__popcll(m_idle), assigned = 0;
+                bool got = false, my_shadow = false; uint32_t my_w = 0, my_q = 0;
+                for (int pass = 0; pass < 4 && remaining > 0; pass++) {
+                    if (w_next == w_end) {
+                        if (c_next == c_end) {
+                            uint32_t c = 0;
+                            if (lane == 0) c = atomicAdd(head, batch);
+                            c_next = wave_first(c) + n_waves * batch; c_end = c_next + batch;
+                        }
+                        take_chunk(c_next++);
+                        if (exhausted) break;
+                    }
+                    const uint32_t take = min(w_end - w_next, remaining);
+                    if (!have && !got && rank >= assigned && rank < assigned + take) { got = true; my_w = w_next + (rank - assigned); my_shadow = chunk_shadow; my_q = q_base; }
+                    w_next += take; assigned += take; remaining -= take;
+                }
+                if (got) {
+                    bool valid;
+                    if (!my_shadow) {
+                        slot = my_w;
+                        const float4 rd = ld_s(&pool.ray_d[my_w]);
+                        valid = (__float_as_uint(rd.w) & 1u) != 0u;
+                        const float4 ro = ld_s(&pool.ray_o[my_w]);
+                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; htri = -1;
+                    } else {
+                        slot = ld_s(&pool.shadow_queue[my_q + my_w]);
+                        const float4 ro = ld_s(&pool.sq_o[my_q + my_w]), sd = ld_s(&pool.sq_d[my_q + my_w]);
+                        o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; htri = __float_as_int(ro.w); valid = true;
+                    }
+                    if (valid) {
+                        const float tiny = 1e-30f;
+                        idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+                        idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+                        idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+                        // the visiting order only matters to closest-hit rays (Render.cpp:125 asks whether the light is visible at all):
+                        // any-hit rays keep octant 0, i.e. slot order -- and a wave that carries no closest-hit ray skips the permutation
+                        oct = any ? 0u : ((idx < 0.0f ? 1u : 0u) | (idy < 0.0f ? 2u : 0u) | (idz < 0.0f ? 4u : 0u));
+                        v2u bottom; bottom.x = 0u; bottom.y = 0u;
+                        stk[0] = bottom; sp = 1;
+                        cur_x = 0u; cur_y = 1u;                          // "child 0 of base 0, no inner siblings": the root
+                        t_x = 0u; t_y = 0u;
+                        hu = 0.f; hv = 0.f; blocked = false;
+                        have = true;
+                    }
+                }
+            }
+            WF_TICK(t_refill)
+            if (exhausted && __ballot(have) == 0) break;
+            continue;
+        }
+
+        if (n_leaf >= (int)tune.leaf_at || n_inner == 0 || (speculate && n_pend >= (int)tune.pend_cap)) {
+            // ------------------------------------------------------------------ leaf block: every lane with a parked leaf group tests ONE of its leaves
+#ifdef WF_SCHED_STATS
+            x_leaf++; if (at_leaf) n_tri++;
+#endif
+            if (at_leaf) {
+                const uint32_t s = (uint32_t)__builtin_ctz(t_y >> 24);                   // leaves in slot order (any order gives the same result)
+                const uint32_t below = (1u << s) - 1u;
+                const uint32_t first = t_x + (uint32_t)__popc((t_y >> 8) & below) + 2u * (uint32_t)__popc((t_y >> 16) & below);
+                const uint32_t cnt = ((t_y >> (8u + s)) & 1u) + 2u * ((t_y >> (16u + s)) & 1u);
+                t_y &= ~(1u << (24u + s));
+                if ((t_y >> 24) == 0u) t_y = 0u;
+                bool done = false;
+#pragma unroll 1
+                for (uint32_t i = 0; i < cnt && !done; i += 2) {
+                    const int ta = (int)(first + i), tb = ta + 1;
+                    const bool use_a = !(any && ta == htri), use_b = i + 1 < cnt && !(any && tb == htri);   // any-hit rays keep their `skip` triangle in htri
+                    const float4* T = sc.tri_isect + 3 * (size_t)ta;
+                    float4 v0a = make_float4(0, 0, 0, 0), e1a = v0a, e2a = v0a, v0b = v0a, e1b = v0a, e2b = v0a;
+                    if (use_a) { v0a = T[0]; e1a = T[1]; e2a = T[2]; }
+                    if (use_b) { v0b = T[3]; e1b = T[4]; e2b = T[5]; }
+#ifndef WF_SCHED_STATS
+                    if (COUNT) n_tri += (use_a ? 1u : 0u) + (use_b ? 1u : 0u);
+#endif
+                    if (use_a) {
+                        const TriTest r = tri_test(v0a, e1a, e2a, o, d);
+                        if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }                     // Triangle::isIntersect
+                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ta | __float_as_int(v0a.w); hu = r.u; hv = r.v; }   // Triangle::hit; v0.w = lobe class << 28
+                    }
+                    if (use_b && !done) {
+                        const TriTest r = tri_test(v0b, e1b, e2b, o, d);
+                        if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }
+                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = tb | __float_as_int(v0b.w); hu = r.u; hv = r.v; }
+                    }
+                }
+                if (done) { cur_y = 0u; t_y = 0u; }                      // any-hit: stop at the first occluder
+                else WF8_PARK()                                          // the group is worked off and another one was waiting on top of the stack
+            }
+            WF_TICK(t_leaf)
+            continue;
+        }
+
+        // ---------------------------------------------------------------------- inner-node block: one 80-B record = eight child boxes
+        int keep = (int)tune.inner_keep;
+        const bool order_matters = __ballot(have && !any) != 0;
+        do {
+#ifdef WF_SCHED_STATS
+            x_inner++; if (at_inner) n_box++;
+#endif
+            if (have && (cur_y & 0xffu) != 0u && (speculate || t_y == 0u)) {
+                // next child of the group on top: lowest pending bit j = slot j ^ oct; its record = base + rank among the inner slots
+                const uint32_t j = (uint32_t)__builtin_ctz(cur_y);
+                const uint32_t s = j ^ oct;
+                const uint32_t node = cur_x + (uint32_t)__popc((cur_y >> 8) & ((1u << s) - 1u));
+                cur_y &= cur_y - 1u;
+                v4f R0, R1, R2, R3, R4;
+                if (node < MCPT_TOP_NODES8) { R0 = top[node]; R1 = top[MCPT_TOP_NODES8 + node]; R2 = top[2 * MCPT_TOP_NODES8 + node]; R3 = top[3 * MCPT_TOP_NODES8 + node]; R4 = top[4 * MCPT_TOP_NODES8 + node]; }
+                else { glb_cf4* n = gnodes + 5 * (size_t)node; R0 = n[0]; R1 = n[1]; R2 = n[2]; R3 = n[3]; R4 = n[4]; }
+                const uint32_t sxy = __float_as_uint(R0.w), masks = __float_as_uint(R1.w);
+                const float ax = __uint_as_float(sxy & 0xffff0000u) * idx, ay = __uint_as_float(sxy << 16) * idy, az = __uint_as_float(__float_as_uint(R1.z) & 0xffff0000u) * idz;
+                const float bx = (R0.x - o.x) * idx, by = (R0.y - o.y) * idy, bz = (R0.z - o.z) * idz;
+                const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
+                // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise
+                const uint32_t xl0 = __float_as_uint(R2.x), xl1 = __float_as_uint(R2.y), xh0 = __float_as_uint(R2.z), xh1 = __float_as_uint(R2.w);
+                const uint32_t yl0 = __float_as_uint(R3.x), yl1 = __float_as_uint(R3.y), yh0 = __float_as_uint(R3.z), yh1 = __float_as_uint(R3.w);
+                const uint32_t zl0 = __float_as_uint(R4.x), zl1 = __float_as_uint(R4.y), zh0 = __float_as_uint(R4.z), zh1 = __float_as_uint(R4.w);
+                const uint32_t nx0 = ngx ? xh0 : xl0, nx1 = ngx ? xh1 : xl1, fx0 = ngx ? xl0 : xh0, fx1 = ngx ? xl1 : xh1;
+                const uint32_t ny0 = ngy ? yh0 : yl0, ny1 = ngy ? yh1 : yl1, fy0 = ngy ? yl0 : yh0, fy1 = ngy ? yl1 : yh1;
+                const uint32_t nz0 = ngz ? zh0 : zl0, nz1 = ngz ? zh1 : zl1, fz0 = ngz ? zl0 : zh0, fz1 = ngz ? zl1 : zh1;
+                uint32_t m = 0u;
+#define WF8_CHILD(K, NX, FX, NY, FY, NZ, FZ)                                                                                         \
+                {                                                                                                                    \
+                    const float t0x = fmaf((float)((NX >> (8 * (K & 3))) & 0xffu), ax, bx), t1x = fmaf((float)((FX >> (8 * (K & 3))) & 0xffu), ax, bx); \
+                    const float t0y = fmaf((float)((NY >> (8 * (K & 3))) & 0xffu), ay, by), t1y = fmaf((float)((FY >> (8 * (K & 3))) & 0xffu), ay, by); \
+                    const float t0z = fmaf((float)((NZ >> (8 * (K & 3))) & 0xffu), az, bz), t1z = fmaf((float)((FZ >> (8 * (K & 3))) & 0xffu), az, bz); \
+                    const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 1e-4f));                                                      \
+                    const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));                                                       \
+                    m |= tn <= tf ? (1u << K) : 0u;                                                                                  \
+                }
+                WF8_CHILD(0, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(1, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(2, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(3, nx0, fx0, ny0, fy0, nz0, fz0)
+                WF8_CHILD(4, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(5, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(6, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(7, nx1, fx1, ny1, fy1, nz1, fz1)
+#undef WF8_CHILD
+                const uint32_t leaf_slots = ((masks >> 8) | (masks >> 16)) & 0xffu;
+#ifndef WF_SCHED_STATS
+                if (COUNT) n_box += (uint32_t)__popc((masks & 0xffu) | leaf_slots);
+#endif
+                uint32_t mi = m & masks & 0xffu;                         // hit inner children, slot order
+                const uint32_t ml = m & leaf_slots;                      // hit leaf children (an empty slot's inverted box cannot be hit; the mask keeps that exact)
+                if (order_matters) {                                     // bit j <- slot j ^ oct (wave-uniform branch; identity for any-hit rays, whose oct is 0)
+                    const uint32_t s1 = ((mi & 0x55u) << 1) | ((mi >> 1) & 0x55u); mi = (oct & 1u) ? s1 : mi;
+                    const uint32_t s2 = ((mi & 0x33u) << 2) | ((mi >> 2) & 0x33u); mi = (oct & 2u) ? s2 : mi;
+                    const uint32_t s4 = ((mi & 0x0fu) << 4) | (mi >> 4);           mi = (oct & 4u) ? s4 : mi;
+                }
+                const uint32_t gn_y = (masks << 8) | mi;                 // (the count planes ride along in bits 16-31; every use masks them off)
+                const uint32_t tn_y = ml ? ((masks & 0x00ffff00u) | (ml << 24)) : 0u;
+                const bool keep_cur = (cur_y & 0xffu) != 0u;             // siblings of the child just taken are still pending
+                const bool t_park = tn_y != 0u && t_y == 0u, t_push = tn_y != 0u && t_y != 0u;
+                v2u e_cur, e_tn; e_cur.x = cur_x; e_cur.y = cur_y; e_tn.x = __float_as_uint(R1.y); e_tn.y = tn_y;
+                if (sp + 2 <= WF8_LDS_STACK) {
+                    // common case, branch-free: store both candidates, advance the stack pointer only past the real ones
+                    stk[sp * WF_TRACE_BLOCK] = e_cur; sp += keep_cur ? 1 : 0;
+                    stk[sp * WF_TRACE_BLOCK] = e_tn;  sp += t_push ? 1 : 0;
+                    const v2u below_top = stk[(sp - 1) * WF_TRACE_BLOCK];
+                    if (mi) { cur_x = __float_as_uint(R1.x); cur_y = gn_y; } else { cur_x = below_top.x; cur_y = below_top.y; sp--; }
+                } else {                                                   // rare: near the LDS limit -> entries may go to the overflow area
+                    if (keep_cur) { if (sp < WF8_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = e_cur; else { OVF8(sp - WF8_LDS_STACK) = e_cur; if (COUNT) n_spill++; } sp++; }
+                    if (t_push) { if (sp < WF8_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = e_tn; else { OVF8(sp - WF8_LDS_STACK) = e_tn; if (COUNT) n_spill++; } sp++; }
+                    if (mi) { cur_x = __float_as_uint(R1.x); cur_y = gn_y; } else WF8_POP()
+                }
+                if (t_park) { t_x = e_tn.x; t_y = tn_y; }
+                WF8_PARK()
+#ifdef WF_DUMMY_VALU    /* regime probe: N extra VALU issues per inner step (independent of everything, results discarded) */
+                { float dz = idx;
+#pragma unroll
+                  for (int k = 0; k < WF_DUMMY_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dz));
+                  asm volatile("" :: "v"(dz)); }
+#endif
+            }
+            const bool still = have && (cur_y & 0xffu) != 0u && (speculate || t_y == 0u);
+            if (greedy) {
+                const int cl = __popcll(__ballot(have && t_y != 0u && !still)), ci = __popcll(__ballot(still));
+                const int cf = exhausted ? 0 : 64 - cl - ci;
+                keep = (cl > cf ? cl : cf) + 1;
+            }
+            if (__popcll(__ballot(still)) < keep) break;
+        } while (true);
+        WF_TICK(t_inner)
+    }
+
+    if (COUNT) {
+        unsigned long long b = n_box, t = n_tri, sx = n_spill;
+        for (int off = 32; off > 0; off >>= 1) { b += __shfl_xor(b, off, 64); t += __shfl_xor(t, off, 64); sx += __shfl_xor(sx, off, 64); }
+        if (lane == 0) {
+            DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1)); atomicAdd(&g->box_tests, b); atomicAdd(&g->tri_tests, t);
+            if (sx) atomicAdd(&g->stack_spills, sx);
+#ifdef WF_SCHED_STATS   // tools/sched_stats.py: the shade-side counters are re-purposed in this diagnostic build
+            atomicAdd(&g->paths, wall_clock64() - t_start);
+            atomicAdd(&g->shaded_hits, (unsigned long long)x_inner); atomicAdd(&g->texel_fetches, (unsigned long long)x_leaf);
+            atomicAdd(&g->self_shadow_tests, (unsigned long long)x_refill); atomicAdd(&g->self_shadow_hits, (unsigned long long)l_refill);
+            atomicAdd(&g->debug[0], t_inner); atomicAdd(&g->debug[1], t_leaf); atomicAdd(&g->debug[2], t_refill);
+#endif
+        }
+    }
+}
+#undef OVF8
+#undef WF8_POP
+#undef WF8_PARK
+#undef WF_TICK
 // ====================================================================================================== launchers
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
                            float4* accum, DevCounters* cnt, hipStream_t stream) {
@@ -852,19 +1172,30 @@ hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const Path
 }
 hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,
                            DevCounters* cnt, uint32_t grid_blocks, int* stack_overflow, hipStream_t stream) {
+    if (sc.n_nodes8 > 0) {                                               // the context's scene carries ONE wide tree: the 8-wide one unless MCPT_BVH_WIDTH=4 built the other
+        if (count) hipLaunchKernelGGL(wf_trace8_kernel<true>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
+        else hipLaunchKernelGGL(wf_trace8_kernel<false>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
+        return hipGetLastError();
+    }
     if (count) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
     else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
     return hipGetLastError();
 }
-int wf_trace_blocks_per_cu(bool count) {
+int wf_trace_blocks_per_cu(bool count, uint32_t width) {
     int n = 0;
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, WF_TRACE_BLOCK, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<false>, WF_TRACE_BLOCK, 0);
+    hipError_t e;
+    if (width == 8) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace8_kernel<true>, WF_TRACE_BLOCK, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace8_kernel<false>, WF_TRACE_BLOCK, 0);
+    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, WF_TRACE_BLOCK, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<false>, WF_TRACE_BLOCK, 0);
     if (e != hipSuccess || n <= 0) n = 1;
     return n;
 }
 uint32_t wf_trace_block_threads() { return WF_TRACE_BLOCK; }
-uint32_t wf_trace_overflow_levels(uint32_t bvh4_depth) {   // worst case: 3 deferred children per level of the 4-wide tree
-    const uint32_t need = 3 * bvh4_depth + 4;
-    return need > WF_LDS_STACK ? need - WF_LDS_STACK : 1;
+// Bytes of the global stack-overflow area per trace lane.  4-wide tree: one 4-B entry per deferred child, 3 per level worst case.  8-wide
+// tree: one 8-B group per level for the pending siblings plus one for a leaf group found while another is parked.
+size_t wf_trace_overflow_bytes_per_lane(uint32_t depth, uint32_t width) {
+    if (width == 8) { const uint32_t need = 2 * depth + 3; return size_t(need > WF8_LDS_STACK ? need - WF8_LDS_STACK : 1) * 8; }
+    const uint32_t need = 3 * depth + 4;
+    return size_t(need > WF_LDS_STACK ? need - WF_LDS_STACK : 1) * 4;
 }

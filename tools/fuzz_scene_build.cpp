@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
         const mcpt_status st = build_host_scene(&d, hs, err);
         if (st != MCPT_OK) { rejected++; continue; }
         accepted++;
-        const std::string why = validate_bvh4(hs);
+        const std::string why = validate_wide_bvh(hs);
         if (!why.empty()) { unsound++; std::printf("case %d kind %d: accepted but tree unsound: %s\n", c, kind, why.c_str()); }
     }
     std::printf("%d cases: %d accepted, %d rejected, %d unsound\n", cases, accepted, rejected, unsound);

@@ -24,4 +24,4 @@ print("%-40s %s tris=%d nodes=%d depth=%d bvh %.0f ms  spp=%d  best %.2f ms  %.1
     os.path.basename(os.environ.get("MCPT_LIB_PATH", "default")), name, i.n_tris, i.n_nodes, i.bvh_depth, i.bvh_build_ms, spp, best,
     c.rays / best / 1e3, c.paths / best / 1e3, c.rays / c.paths), flush=True)
 print("   iterations %d launches %d   trace %.3f ms/launch  shade %.3f ms/launch" % (c.iterations, c.launches, c.trace_ms_total / max(1, c.iterations), c.shade_ms_total / max(1, c.iterations)))
-if c.box_tests: print("   box/ray %.2f tri/ray %.2f" % (c.box_tests / c.rays, c.tri_tests / c.rays))
+if c.box_tests: print("   box/ray %.2f tri/ray %.2f  stack spills/ray %.4f" % (c.box_tests / c.rays, c.tri_tests / c.rays, c.stack_spills / c.rays))
