@@ -419,7 +419,7 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
         }
         f4h* r = &n8[5 * size_t(w.rec)];
         r[0] = {lo[0], lo[1], lo[2], from_u32((bf16_pow2(ebits[0]) << 16) | bf16_pow2(ebits[1]))};
-        r[1] = {from_u32(child_base), from_u32(tri_base), from_u32(bf16_pow2(ebits[2]) << 16), from_u32(imask | (p0 << 8) | (p1 << 16))};
+        r[1] = {from_u32(child_base), from_u32(tri_base), from_u32(bf16_pow2(ebits[2]) << 16), from_u32(imask | (p0 << 8) | (p1 << 16) | ((p0 | p1) << 24))};
         r[2] = {from_u32(q[0][0][0]), from_u32(q[0][0][1]), from_u32(q[0][1][0]), from_u32(q[0][1][1])};   // x: lo 0-3, lo 4-7, hi 0-3, hi 4-7
         r[3] = {from_u32(q[1][0][0]), from_u32(q[1][0][1]), from_u32(q[1][1][0]), from_u32(q[1][1][1])};   // y
         r[4] = {from_u32(q[2][0][0]), from_u32(q[2][0][1]), from_u32(q[2][1][0]), from_u32(q[2][1][1])};   // z

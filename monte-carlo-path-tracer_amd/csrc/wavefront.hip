@@ -860,8 +860,18 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #define WF8_LDS_STACK 6
 #endif
 #ifndef MCPT_TOP_NODES8
-#define MCPT_TOP_NODES8 192         // records numbered breadth-first by the builder; 192 x 80 B = 15 KB of LDS
+#define MCPT_TOP_NODES8 160         // records numbered breadth-first by the builder; 160 x 80 B = 12.5 KB of LDS
 #endif
+#define WF8_CHILD(K, NX, FX, NY, FY, NZ, FZ)                                                                                         \
+        {                                                                                                                    \
+            const float t0x = fmaf((float)((NX >> (8 * (K & 3))) & 0xffu), ax, bx), t1x = fmaf((float)((FX >> (8 * (K & 3))) & 0xffu), ax, bx); \
+            const float t0y = fmaf((float)((NY >> (8 * (K & 3))) & 0xffu), ay, by), t1y = fmaf((float)((FY >> (8 * (K & 3))) & 0xffu), ay, by); \
+            const float t0z = fmaf((float)((NZ >> (8 * (K & 3))) & 0xffu), az, bz), t1z = fmaf((float)((FZ >> (8 * (K & 3))) & 0xffu), az, bz); \
+            const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 1e-4f));                                                      \
+            const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));                                                       \
+            /* m = 2 m + (tn <= tf): the compare's carry shifted in by ONE add-with-carry (slot 7 first, so slot s ends up in bit s) */ \
+            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(tn), "v"(tf) : "vcc");      \
+        }
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
                                                                    int* __restrict__ stack_overflow) {
@@ -880,12 +890,17 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     glb_cf4* gnodes = (glb_cf4*)sc.nodes8;
     const int n_top = sc.n_nodes8 < MCPT_TOP_NODES8 ? sc.n_nodes8 : MCPT_TOP_NODES8;
     for (int i = threadIdx.x; i < 5 * n_top; i += WF_TRACE_BLOCK) s_top[(i % 5) * MCPT_TOP_NODES8 + (i / 5)] = sc.nodes8[i];
+    // the octant permutation of a hit mask (bit j <- slot j ^ oct) is one LDS byte read: three conditional swaps in registers cost 11 VALU
+    // issues per step and 1.2 % of the step time
+    __shared__ unsigned char s_perm[8 * 256];
+    for (int i = threadIdx.x; i < 8 * 256; i += WF_TRACE_BLOCK) { const uint32_t oc = (uint32_t)i >> 8, mm = (uint32_t)i & 255u; uint32_t rr = 0; for (uint32_t jj = 0; jj < 8; jj++) rr |= ((mm >> (jj ^ oc)) & 1u) << jj; s_perm[i] = (unsigned char)rr; }
     __syncthreads();
 #ifdef WF_SCHED_STATS
     const unsigned long long t_start = wall_clock64();
 #endif
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = pool.P;
+    const uint32_t sq_off = (uint32_t)(pool.sq_o - pool.ray_o);      // one allocation (mcpt_api.cpp); also sq_d - ray_d
     // the ray list and its chunks: exactly as in wf_trace_kernel
     const uint32_t n_ext_chunks = P / WF_SHADE_BLOCK;
     const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
@@ -937,6 +952,67 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     const bool speculate = tune.pend_cap != 0u;      // MCPT_WF_PEND=0 (developer knob): a lane with a parked leaf group waits for the leaf block
     const bool greedy = tune.policy == 1;
 
+    // One inner step in two halves, so that the refill block can put its own loads between them (see there): `issue` picks the next child of
+    // the group on top of the stack and requests its record, `consume` tests the eight boxes and updates the stack.
+    v4f R0, R1, R2, R3, R4;
+    bool order_matters = true;
+    auto inner_issue = [&]() __attribute__((always_inline)) {
+        // next child of the group on top: lowest pending bit j = slot j ^ oct; its record = base + rank among the inner slots
+        const uint32_t j = (uint32_t)__builtin_ctz(cur_y);
+        const uint32_t s = j ^ oct;
+        const uint32_t node = cur_x + (uint32_t)__popc((cur_y >> 8) & ((1u << s) - 1u));
+        cur_y &= cur_y - 1u;
+        if (node < MCPT_TOP_NODES8) { R0 = top[node]; R1 = top[MCPT_TOP_NODES8 + node]; R2 = top[2 * MCPT_TOP_NODES8 + node]; R3 = top[3 * MCPT_TOP_NODES8 + node]; R4 = top[4 * MCPT_TOP_NODES8 + node]; }
+        else { glb_cf4* n = gnodes + 5 * (size_t)node; R0 = n[0]; R1 = n[1]; R2 = n[2]; R3 = n[3]; R4 = n[4]; }
+    };
+    auto inner_consume = [&]() __attribute__((always_inline)) {
+        const uint32_t sxy = __float_as_uint(R0.w), masks = __float_as_uint(R1.w);
+        const float ax = __uint_as_float(sxy & 0xffff0000u) * idx, ay = __uint_as_float(sxy << 16) * idy, az = __uint_as_float(__float_as_uint(R1.z) & 0xffff0000u) * idz;
+        const float bx = (R0.x - o.x) * idx, by = (R0.y - o.y) * idy, bz = (R0.z - o.z) * idz;
+        const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
+        // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise
+        const uint32_t xl0 = __float_as_uint(R2.x), xl1 = __float_as_uint(R2.y), xh0 = __float_as_uint(R2.z), xh1 = __float_as_uint(R2.w);
+        const uint32_t yl0 = __float_as_uint(R3.x), yl1 = __float_as_uint(R3.y), yh0 = __float_as_uint(R3.z), yh1 = __float_as_uint(R3.w);
+        const uint32_t zl0 = __float_as_uint(R4.x), zl1 = __float_as_uint(R4.y), zh0 = __float_as_uint(R4.z), zh1 = __float_as_uint(R4.w);
+        const uint32_t nx0 = ngx ? xh0 : xl0, nx1 = ngx ? xh1 : xl1, fx0 = ngx ? xl0 : xh0, fx1 = ngx ? xl1 : xh1;
+        const uint32_t ny0 = ngy ? yh0 : yl0, ny1 = ngy ? yh1 : yl1, fy0 = ngy ? yl0 : yh0, fy1 = ngy ? yl1 : yh1;
+        const uint32_t nz0 = ngz ? zh0 : zl0, nz1 = ngz ? zh1 : zl1, fz0 = ngz ? zl0 : zh0, fz1 = ngz ? zl1 : zh1;
+        uint32_t m = 0u;
+        WF8_CHILD(7, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(6, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(5, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(4, nx1, fx1, ny1, fy1, nz1, fz1)
+        WF8_CHILD(3, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(2, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(1, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(0, nx0, fx0, ny0, fy0, nz0, fz0)
+        const uint32_t leaf_slots = masks >> 24;                 // = p0 | p1, stored by the builder
+#ifndef WF_SCHED_STATS
+        if (COUNT) n_box += (uint32_t)__popc((masks & 0xffu) | leaf_slots);
+#endif
+        uint32_t mi = m & masks & 0xffu;                         // hit inner children, slot order
+        const uint32_t ml = m & leaf_slots;                      // hit leaf children (an empty slot's inverted box cannot be hit; the mask keeps that exact)
+        if (order_matters) mi = s_perm[(oct << 8) | mi];         // bit j <- slot j ^ oct (wave-uniform branch; identity for any-hit rays, whose oct is 0)
+        const uint32_t gn_y = (masks << 8) | mi;                 // (the count planes ride along in bits 16-31; every use masks them off)
+        const uint32_t tn_y = ml ? ((masks & 0x00ffff00u) | (ml << 24)) : 0u;
+        const bool keep_cur = (cur_y & 0xffu) != 0u;             // siblings of the child just taken are still pending
+        const bool t_park = tn_y != 0u && t_y == 0u, t_push = tn_y != 0u && t_y != 0u;
+        v2u e_cur, e_tn; e_cur.x = cur_x; e_cur.y = cur_y; e_tn.x = __float_as_uint(R1.y); e_tn.y = tn_y;
+        if (sp + 2 <= WF8_LDS_STACK) {
+            // common case, branch-free: store both candidates, advance the stack pointer only past the real ones
+            stk[sp * WF_TRACE_BLOCK] = e_cur; sp += keep_cur ? 1 : 0;
+            stk[sp * WF_TRACE_BLOCK] = e_tn;  sp += t_push ? 1 : 0;
+            const v2u below_top = stk[(sp - 1) * WF_TRACE_BLOCK];
+            if (mi) { cur_x = __float_as_uint(R1.x); cur_y = gn_y; } else { cur_x = below_top.x; cur_y = below_top.y; sp--; }
+        } else {                                                   // rare: near the LDS limit -> entries may go to the overflow area
+            if (keep_cur) { if (sp < WF8_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = e_cur; else { OVF8(sp - WF8_LDS_STACK) = e_cur; if (COUNT) n_spill++; } sp++; }
+            if (t_push) { if (sp < WF8_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = e_tn; else { OVF8(sp - WF8_LDS_STACK) = e_tn; if (COUNT) n_spill++; } sp++; }
+            if (mi) { cur_x = __float_as_uint(R1.x); cur_y = gn_y; } else WF8_POP()
+        }
+        if (t_park) { t_x = e_tn.x; t_y = tn_y; }
+        WF8_PARK()
+#ifdef WF_DUMMY_VALU    /* regime probe: N extra VALU issues per inner step (independent of everything, results discarded) */
+        { float dz = idx;
+#pragma unroll
+          for (int k = 0; k < WF_DUMMY_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dz));
+          asm volatile("" :: "v"(dz)); }
+#endif
+    };
+
     uint32_t watchdog = 0;
     for (;;) {
         if (++watchdog > (1u << 24)) { if (lane == 0) ctl->pad[0] = 1u; break; }
@@ -960,11 +1036,16 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 }
                 have = false;
             }
+            // New rays for the idle lanes -- with an inner step of the busy lanes INSIDE the round trip.  The ray records stream from HBM
+            // (~6 000 cycles per refill, 30 % of a wave's time) and vector-memory results return in issue order, so the only work that can
+            // overlap them is work whose own loads were requested first: the busy lanes pick their next node and request its record, THEN the
+            // ray records are requested, then the boxes are tested while the rays are still in flight.  For the compiler to wait for the node
+            // records only (s_waitcnt vmcnt(3)) the three ray loads are unconditional: a lane without a new ray reads entry 0.
+            bool got = false, my_shadow = false; uint32_t my_w = 0, my_q = 0;
             if (!exhausted) {
                 const uint64_t m_idle = __ballot(!have);
                 const uint32_t rank = lane_rank(m_idle);
                 uint32_t remaining = (uint32_t)__popcll(m_idle), assigned = 0;
-                bool got = false, my_shadow = false; uint32_t my_w = 0, my_q = 0;
                 for (int pass = 0; pass < 4 && remaining > 0; pass++) {
                     if (w_next == w_end) {
                         if (c_next == c_end) {
@@ -979,34 +1060,49 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     if (!have && !got && rank >= assigned && rank < assigned + take) { got = true; my_w = w_next + (rank - assigned); my_shadow = chunk_shadow; my_q = q_base; }
                     w_next += take; assigned += take; remaining -= take;
                 }
-                if (got) {
-                    bool valid;
-                    if (!my_shadow) {
-                        slot = my_w;
-                        const float4 rd = ld_s(&pool.ray_d[my_w]);
-                        valid = (__float_as_uint(rd.w) & 1u) != 0u;
-                        const float4 ro = ld_s(&pool.ray_o[my_w]);
-                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; htri = -1;
-                    } else {
-                        slot = ld_s(&pool.shadow_queue[my_q + my_w]);
-                        const float4 ro = ld_s(&pool.sq_o[my_q + my_w]), sd = ld_s(&pool.sq_d[my_q + my_w]);
-                        o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; htri = __float_as_int(ro.w); valid = true;
-                    }
-                    if (valid) {
-                        const float tiny = 1e-30f;
-                        idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
-                        idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
-                        idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
-                        // the visiting order only matters to closest-hit rays (Render.cpp:125 asks whether the light is visible at all):
-                        // any-hit rays keep octant 0, i.e. slot order -- and a wave that carries no closest-hit ray skips the permutation
-                        oct = any ? 0u : ((idx < 0.0f ? 1u : 0u) | (idy < 0.0f ? 2u : 0u) | (idz < 0.0f ? 4u : 0u));
-                        v2u bottom; bottom.x = 0u; bottom.y = 0u;
-                        stk[0] = bottom; sp = 1;
-                        cur_x = 0u; cur_y = 1u;                          // "child 0 of base 0, no inner siblings": the root
-                        t_x = 0u; t_y = 0u;
-                        hu = 0.f; hv = 0.f; blocked = false;
-                        have = true;
-                    }
+            }
+            order_matters = __ballot(have && !any) != 0;
+            const bool step = have && (cur_y & 0xffu) != 0u && (speculate || t_y == 0u);
+#ifndef WF8_NO_FUSED_REFILL
+            if (step) inner_issue();
+#endif
+            const uint32_t iq = my_shadow ? my_q + my_w : 0u, ia = got ? (my_shadow ? sq_off + iq : my_w) : 0u;   // (shadow records follow the extend records: sq_o = ray_o + sq_off)
+            const float4 ro = ld_s(pool.ray_o + ia);
+            const float4 rd = ld_s(pool.ray_d + ia);
+            const uint32_t qs = ld_s(pool.shadow_queue + iq);
+#ifndef WF8_NO_FUSED_REFILL
+            if (step) {
+                inner_consume();
+#ifdef WF_SCHED_STATS
+                n_box++;
+#endif
+            }
+#endif
+            if (got) {
+                bool valid;
+                o = xyz(ro); d = xyz(rd);
+                if (!my_shadow) {                                        // extend ray of slot my_w
+                    slot = my_w;
+                    valid = (__float_as_uint(rd.w) & 1u) != 0u;
+                    tmax = 3.0e38f; any = false; htri = -1;
+                } else {                                                 // queued shadow ray: origin.w = the light triangle to skip, direction.w = t2
+                    slot = qs;
+                    tmax = rd.w; any = true; htri = __float_as_int(ro.w); valid = true;
+                }
+                if (valid) {
+                    const float tiny = 1e-30f;
+                    idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+                    idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+                    idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+                    // the visiting order only matters to closest-hit rays (Render.cpp:125 asks whether the light is visible at all):
+                    // any-hit rays keep octant 0, i.e. slot order -- and a wave that carries no closest-hit ray skips the permutation
+                    oct = any ? 0u : ((idx < 0.0f ? 1u : 0u) | (idy < 0.0f ? 2u : 0u) | (idz < 0.0f ? 4u : 0u));
+                    v2u bottom; bottom.x = 0u; bottom.y = 0u;
+                    stk[0] = bottom; sp = 1;
+                    cur_x = 0u; cur_y = 1u;                              // "child 0 of base 0, no inner siblings": the root
+                    t_x = 0u; t_y = 0u;
+                    hu = 0.f; hv = 0.f; blocked = false;
+                    have = true;
                 }
             }
             WF_TICK(t_refill)
@@ -1058,80 +1154,13 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 
         // ---------------------------------------------------------------------- inner-node block: one 80-B record = eight child boxes
         int keep = (int)tune.inner_keep;
-        const bool order_matters = __ballot(have && !any) != 0;
+        order_matters = __ballot(have && !any) != 0;
         do {
 #ifdef WF_SCHED_STATS
             x_inner++; if (at_inner) n_box++;
 #endif
-            if (have && (cur_y & 0xffu) != 0u && (speculate || t_y == 0u)) {
-                // next child of the group on top: lowest pending bit j = slot j ^ oct; its record = base + rank among the inner slots
-                const uint32_t j = (uint32_t)__builtin_ctz(cur_y);
-                const uint32_t s = j ^ oct;
-                const uint32_t node = cur_x + (uint32_t)__popc((cur_y >> 8) & ((1u << s) - 1u));
-                cur_y &= cur_y - 1u;
-                v4f R0, R1, R2, R3, R4;
-                if (node < MCPT_TOP_NODES8) { R0 = top[node]; R1 = top[MCPT_TOP_NODES8 + node]; R2 = top[2 * MCPT_TOP_NODES8 + node]; R3 = top[3 * MCPT_TOP_NODES8 + node]; R4 = top[4 * MCPT_TOP_NODES8 + node]; }
-                else { glb_cf4* n = gnodes + 5 * (size_t)node; R0 = n[0]; R1 = n[1]; R2 = n[2]; R3 = n[3]; R4 = n[4]; }
-                const uint32_t sxy = __float_as_uint(R0.w), masks = __float_as_uint(R1.w);
-                const float ax = __uint_as_float(sxy & 0xffff0000u) * idx, ay = __uint_as_float(sxy << 16) * idy, az = __uint_as_float(__float_as_uint(R1.z) & 0xffff0000u) * idz;
-                const float bx = (R0.x - o.x) * idx, by = (R0.y - o.y) * idy, bz = (R0.z - o.z) * idz;
-                const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
-                // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise
-                const uint32_t xl0 = __float_as_uint(R2.x), xl1 = __float_as_uint(R2.y), xh0 = __float_as_uint(R2.z), xh1 = __float_as_uint(R2.w);
-                const uint32_t yl0 = __float_as_uint(R3.x), yl1 = __float_as_uint(R3.y), yh0 = __float_as_uint(R3.z), yh1 = __float_as_uint(R3.w);
-                const uint32_t zl0 = __float_as_uint(R4.x), zl1 = __float_as_uint(R4.y), zh0 = __float_as_uint(R4.z), zh1 = __float_as_uint(R4.w);
-                const uint32_t nx0 = ngx ? xh0 : xl0, nx1 = ngx ? xh1 : xl1, fx0 = ngx ? xl0 : xh0, fx1 = ngx ? xl1 : xh1;
-                const uint32_t ny0 = ngy ? yh0 : yl0, ny1 = ngy ? yh1 : yl1, fy0 = ngy ? yl0 : yh0, fy1 = ngy ? yl1 : yh1;
-                const uint32_t nz0 = ngz ? zh0 : zl0, nz1 = ngz ? zh1 : zl1, fz0 = ngz ? zl0 : zh0, fz1 = ngz ? zl1 : zh1;
-                uint32_t m = 0u;
-#define WF8_CHILD(K, NX, FX, NY, FY, NZ, FZ)                                                                                         \
-                {                                                                                                                    \
-                    const float t0x = fmaf((float)((NX >> (8 * (K & 3))) & 0xffu), ax, bx), t1x = fmaf((float)((FX >> (8 * (K & 3))) & 0xffu), ax, bx); \
-                    const float t0y = fmaf((float)((NY >> (8 * (K & 3))) & 0xffu), ay, by), t1y = fmaf((float)((FY >> (8 * (K & 3))) & 0xffu), ay, by); \
-                    const float t0z = fmaf((float)((NZ >> (8 * (K & 3))) & 0xffu), az, bz), t1z = fmaf((float)((FZ >> (8 * (K & 3))) & 0xffu), az, bz); \
-                    const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 1e-4f));                                                      \
-                    const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));                                                       \
-                    m |= tn <= tf ? (1u << K) : 0u;                                                                                  \
-                }
-                WF8_CHILD(0, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(1, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(2, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(3, nx0, fx0, ny0, fy0, nz0, fz0)
-                WF8_CHILD(4, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(5, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(6, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(7, nx1, fx1, ny1, fy1, nz1, fz1)
-#undef WF8_CHILD
-                const uint32_t leaf_slots = ((masks >> 8) | (masks >> 16)) & 0xffu;
-#ifndef WF_SCHED_STATS
-                if (COUNT) n_box += (uint32_t)__popc((masks & 0xffu) | leaf_slots);
-#endif
-                uint32_t mi = m & masks & 0xffu;                         // hit inner children, slot order
-                const uint32_t ml = m & leaf_slots;                      // hit leaf children (an empty slot's inverted box cannot be hit; the mask keeps that exact)
-                if (order_matters) {                                     // bit j <- slot j ^ oct (wave-uniform branch; identity for any-hit rays, whose oct is 0)
-                    const uint32_t s1 = ((mi & 0x55u) << 1) | ((mi >> 1) & 0x55u); mi = (oct & 1u) ? s1 : mi;
-                    const uint32_t s2 = ((mi & 0x33u) << 2) | ((mi >> 2) & 0x33u); mi = (oct & 2u) ? s2 : mi;
-                    const uint32_t s4 = ((mi & 0x0fu) << 4) | (mi >> 4);           mi = (oct & 4u) ? s4 : mi;
-                }
-                const uint32_t gn_y = (masks << 8) | mi;                 // (the count planes ride along in bits 16-31; every use masks them off)
-                const uint32_t tn_y = ml ? ((masks & 0x00ffff00u) | (ml << 24)) : 0u;
-                const bool keep_cur = (cur_y & 0xffu) != 0u;             // siblings of the child just taken are still pending
-                const bool t_park = tn_y != 0u && t_y == 0u, t_push = tn_y != 0u && t_y != 0u;
-                v2u e_cur, e_tn; e_cur.x = cur_x; e_cur.y = cur_y; e_tn.x = __float_as_uint(R1.y); e_tn.y = tn_y;
-                if (sp + 2 <= WF8_LDS_STACK) {
-                    // common case, branch-free: store both candidates, advance the stack pointer only past the real ones
-                    stk[sp * WF_TRACE_BLOCK] = e_cur; sp += keep_cur ? 1 : 0;
-                    stk[sp * WF_TRACE_BLOCK] = e_tn;  sp += t_push ? 1 : 0;
-                    const v2u below_top = stk[(sp - 1) * WF_TRACE_BLOCK];
-                    if (mi) { cur_x = __float_as_uint(R1.x); cur_y = gn_y; } else { cur_x = below_top.x; cur_y = below_top.y; sp--; }
-                } else {                                                   // rare: near the LDS limit -> entries may go to the overflow area
-                    if (keep_cur) { if (sp < WF8_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = e_cur; else { OVF8(sp - WF8_LDS_STACK) = e_cur; if (COUNT) n_spill++; } sp++; }
-                    if (t_push) { if (sp < WF8_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = e_tn; else { OVF8(sp - WF8_LDS_STACK) = e_tn; if (COUNT) n_spill++; } sp++; }
-                    if (mi) { cur_x = __float_as_uint(R1.x); cur_y = gn_y; } else WF8_POP()
-                }
-                if (t_park) { t_x = e_tn.x; t_y = tn_y; }
-                WF8_PARK()
-#ifdef WF_DUMMY_VALU    /* regime probe: N extra VALU issues per inner step (independent of everything, results discarded) */
-                { float dz = idx;
-#pragma unroll
-                  for (int k = 0; k < WF_DUMMY_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dz));
-                  asm volatile("" :: "v"(dz)); }
-#endif
-            }
+            const bool step = have && (cur_y & 0xffu) != 0u && (speculate || t_y == 0u);
+            if (step) { inner_issue(); inner_consume(); }
             const bool still = have && (cur_y & 0xffu) != 0u && (speculate || t_y == 0u);
             if (greedy) {
                 const int cl = __popcll(__ballot(have && t_y != 0u && !still)), ci = __popcll(__ballot(still));
@@ -1159,6 +1188,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     }
 }
 #undef OVF8
+#undef WF8_CHILD
 #undef WF8_POP
 #undef WF8_PARK
 #undef WF_TICK

@@ -121,71 +121,125 @@ def write_ppm(path: str, img: np.ndarray) -> None:
         f.write(img.tobytes())
 
 
+_P10 = np.array([float("1e%d" % e) for e in range(-40, 41)])          # exact decimal powers (correctly rounded by the parser)
+
+
+def _qv(x) -> np.ndarray:
+    """``_q`` for whole arrays: every element rounded to 9 significant decimal digits and read back, bit for bit what
+    ``float("%.9g" % x)`` gives (checked against it on a sample every time a scene is finished).  x = m * 10^-j with a
+    9-digit integer m: the candidates m0 - 1, m0, m0 + 1 are turned into doubles by ONE correctly rounded division or
+    multiplication by an exact power of ten -- the parser's own fast path -- and the nearest wins (ties to the even m)."""
+    x = np.asarray(x, np.float64)
+    out = x.copy()
+    fast = np.isfinite(x) & (np.abs(x) >= 1e-13) & (np.abs(x) < 1e30)                    # |j| <= 22 below: 10^|j| is an exact double
+    slow = np.isfinite(x) & (x != 0) & ~fast                                           # (a handful of 1e-17s from sin(pi) and the like)
+    if slow.any():
+        out[slow] = [float("%.9g" % v) for v in x[slow].tolist()]
+    a = np.abs(x[fast])
+    if a.size == 0:
+        return out
+    k = np.floor(np.log10(a)).astype(np.int64)
+    k = np.where(a < _P10[k + 40], k - 1, k); k = np.where(a >= _P10[k + 41], k + 1, k)   # guard log10 at powers of ten
+    j = 8 - k
+    pos = j >= 0
+    sc = np.where(pos, _P10[np.where(pos, j, 0) + 40], 1.0); sc2 = np.where(pos, 1.0, _P10[np.where(pos, 0, -j) + 40])
+    m0 = np.rint(np.where(pos, a * sc, a / sc2))
+    best = bd = None
+    for dm in (-1.0, 0.0, 1.0):
+        m = m0 + dm
+        c = np.where(pos, m / sc, m * sc2)
+        d = np.abs(a - c)
+        if best is None:
+            best, bd = c, d
+        else:
+            take = (d < bd) | ((d == bd) & (np.fmod(m, 2.0) == 0.0))
+            best = np.where(take, c, best); bd = np.where(take, d, bd)
+    out[fast] = np.copysign(best, x[fast])
+    return out
+
+
 class _Mesh:
-    """Accumulates unified-index geometry (one v / vn / vt triple per corner index)."""
+    """Accumulates unified-index geometry (one v / vn / vt triple per corner index).  Vertices and faces are kept as numpy
+    blocks in insertion order; the builders below compute whole grids / spheres at once, in the element-wise operation order
+    of the scalar formulas (so the numbers are the ones a per-vertex loop gives) -- a 4 M-triangle scene takes seconds."""
 
     def __init__(self):
-        self.v: List[tuple] = []
-        self.n: List[tuple] = []
-        self.t: List[tuple] = []
-        self.f: List[tuple] = []   # (i0, i1, i2, material)
+        self.v: List[np.ndarray] = []      # (k,3) blocks, not yet rounded to the files' text form
+        self.n: List[np.ndarray] = []
+        self.t: List[np.ndarray] = []      # (k,2)
+        self.f: List[np.ndarray] = []      # (k,4) int blocks: i0, i1, i2, material
+        self.nv = 0
+
+    def add_vertices(self, p, n, uv) -> int:
+        p = np.asarray(p, np.float64).reshape(-1, 3)
+        n = np.broadcast_to(np.asarray(n, np.float64), p.shape) if np.ndim(n) == 1 else np.asarray(n, np.float64).reshape(-1, 3)
+        uv = np.asarray(uv, np.float64).reshape(-1, 2)
+        self.v.append(p); self.n.append(np.array(n)); self.t.append(uv)
+        base = self.nv
+        self.nv += p.shape[0]
+        return base
 
     def add_vertex(self, p, n, uv) -> int:
-        self.v.append(tuple(_q(float(x)) for x in p))
-        self.n.append(tuple(_q(float(x)) for x in n))
-        self.t.append(tuple(_q(float(x)) for x in uv))
-        return len(self.v) - 1
+        return self.add_vertices([tuple(float(x) for x in p)], [tuple(float(x) for x in n)], [tuple(float(x) for x in uv)])
 
     def add_tri(self, a, b, c, mat):
-        self.f.append((a, b, c, mat))
+        self.f.append(np.array([[a, b, c, mat]], np.int64))
 
     def add_quad(self, p0, p1, p2, p3, n, mat, uv=((0, 0), (1, 0), (1, 1), (0, 1))):
         i = [self.add_vertex(p, n, t) for p, t in zip((p0, p1, p2, p3), uv)]
         self.add_tri(i[0], i[1], i[2], mat)
         self.add_tri(i[0], i[2], i[3], mat)
 
+    def _quads(self, idx, mat, first=None, second=None):
+        """Two triangles (a, b, c), (a, c, d) per cell of the vertex-index lattice `idx`, cells in row-major order."""
+        a, b, c, d = idx[:-1, :-1], idx[:-1, 1:], idx[1:, 1:], idx[1:, :-1]
+        m = np.full_like(a, mat)
+        tri = np.stack([np.stack([a, b, c, m], -1), np.stack([a, c, d, m], -1)], 2)      # (rows, cols, 2, 4)
+        keep = np.ones(tri.shape[:3], bool)
+        if first is not None: keep[:, :, 0] = first[:, None]
+        if second is not None: keep[:, :, 1] = second[:, None]
+        self.f.append(tri[keep].reshape(-1, 4).astype(np.int64))
+
+    def add_lattice(self, p, n, uv, mat, first=None, second=None):
+        """(rows, cols, 3) positions / normals and (rows, cols, 2) texture coordinates -> vertices + the cells' triangles."""
+        rows, cols = p.shape[:2]
+        base = self.add_vertices(p.reshape(-1, 3), np.asarray(n, np.float64).reshape(-1, 3) if np.ndim(n) == 3 else n, uv.reshape(-1, 2))
+        self._quads(base + np.arange(rows * cols, dtype=np.int64).reshape(rows, cols), mat, first, second)
+
     def add_grid(self, origin, du, dv, nu, nv, n, mat, uv_scale=1.0):
         """A planar rectangle origin + s*du + t*dv tessellated into nu x nv cells."""
         o = np.asarray(origin, float); du = np.asarray(du, float); dv = np.asarray(dv, float)
-        idx = [[self.add_vertex(o + du * (i / nu) + dv * (j / nv), n, (uv_scale * i / nu, uv_scale * j / nv))
-                for i in range(nu + 1)] for j in range(nv + 1)]
-        for j in range(nv):
-            for i in range(nu):
-                a, b, c, d = idx[j][i], idx[j][i + 1], idx[j + 1][i + 1], idx[j + 1][i]
-                self.add_tri(a, b, c, mat)
-                self.add_tri(a, c, d, mat)
+        ii = np.arange(nu + 1, dtype=np.float64); jj = np.arange(nv + 1, dtype=np.float64)
+        p = (o[None, None, :] + du[None, None, :] * (ii / nu)[None, :, None]) + dv[None, None, :] * (jj / nv)[:, None, None]
+        uv = np.stack(np.broadcast_arrays((uv_scale * ii / nu)[None, :], (uv_scale * jj / nv)[:, None]), -1)
+        self.add_lattice(p, np.asarray(n, np.float64), uv, mat)
 
     def add_uv_sphere(self, center, radius, n_lon, n_lat, mat, flip=False):
         """UV sphere, smooth normals; n_lon*(n_lat-1)*2 triangles."""
         cx, cy, cz = center
-        rows = []
-        for j in range(n_lat + 1):
-            th = math.pi * j / n_lat
-            row = []
-            for i in range(n_lon + 1):
-                ph = 2.0 * math.pi * i / n_lon
-                d = (math.sin(th) * math.cos(ph), math.cos(th), math.sin(th) * math.sin(ph))
-                nn = tuple(-x for x in d) if flip else d
-                row.append(self.add_vertex((cx + radius * d[0], cy + radius * d[1], cz + radius * d[2]), nn,
-                                           (i / n_lon, j / n_lat)))
-            rows.append(row)
-        for j in range(n_lat):
-            for i in range(n_lon):
-                a, b, c, d = rows[j][i], rows[j][i + 1], rows[j + 1][i + 1], rows[j + 1][i]
-                if j != 0:
-                    self.add_tri(a, b, c, mat)
-                if j != n_lat - 1:
-                    self.add_tri(a, c, d, mat)
+        th = [math.pi * j / n_lat for j in range(n_lat + 1)]; ph = [2.0 * math.pi * i / n_lon for i in range(n_lon + 1)]
+        st = np.array([math.sin(x) for x in th])[:, None]; ct = np.array([math.cos(x) for x in th])[:, None]
+        cp = np.array([math.cos(x) for x in ph])[None, :]; sp = np.array([math.sin(x) for x in ph])[None, :]
+        d = np.stack(np.broadcast_arrays(st * cp, ct, st * sp), -1)                   # (n_lat+1, n_lon+1, 3)
+        p = np.stack([cx + radius * d[..., 0], cy + radius * d[..., 1], cz + radius * d[..., 2]], -1)
+        uv = np.stack(np.broadcast_arrays((np.arange(n_lon + 1, dtype=np.float64) / n_lon)[None, :],
+                                          (np.arange(n_lat + 1, dtype=np.float64) / n_lat)[:, None]), -1)
+        jrow = np.arange(n_lat)
+        self.add_lattice(p, -d if flip else d, uv, mat, first=jrow != 0, second=jrow != n_lat - 1)
 
     def finish(self, name, materials, camera, meta=None) -> SceneData:
-        v = np.asarray(self.v, np.float64).reshape(-1, 3)
-        n = np.asarray(self.n, np.float64).reshape(-1, 3)
-        t = np.asarray(self.t, np.float64).reshape(-1, 2)
+        v = np.concatenate(self.v).reshape(-1, 3); n = np.concatenate(self.n).reshape(-1, 3); t = np.concatenate(self.t).reshape(-1, 2)
+        raw = (v, n, t)
+        v, n, t = _qv(v), _qv(n), _qv(t)
+        rng = np.random.RandomState(12345)                                            # the text round trip itself, on a sample
+        for r_, q_ in zip(raw, (v, n, t)):
+            pick = rng.randint(0, r_.size, size=min(r_.size, 4096))
+            assert all(float("%.9g" % a) == b for a, b in zip(r_.ravel()[pick].tolist(), q_.ravel()[pick].tolist())), "_qv departs from the text round trip"
         # the reference keeps the file's face order but needs `usemtl` runs; keep insertion order
-        face = np.zeros((len(self.f), 3, 4), np.int32)
-        for k, (a, b, c, m) in enumerate(self.f):
-            for j, idx in enumerate((a, b, c)):
-                face[k, j, 0] = idx; face[k, j, 1] = idx; face[k, j, 2] = idx; face[k, j, 3] = m
+        f = np.concatenate(self.f).reshape(-1, 4)
+        face = np.zeros((f.shape[0], 3, 4), np.int32)
+        for j in range(3):
+            face[:, j, 0] = f[:, j]; face[:, j, 1] = f[:, j]; face[:, j, 2] = f[:, j]; face[:, j, 3] = f[:, 3]
         return SceneData(name, v, n, t, face, materials, camera, meta or {})
 
 
@@ -314,21 +368,17 @@ def bathroom_stress(width=1920, height=1080, detail=64, tex_size=256) -> SceneDa
     # towel: displaced grid hanging on the left wall (bumpy -> deep, irregular BVH)
     nu = nv = 2 * detail
     o = np.array((0.05, 0.9, 2.0)); du = np.array((0.0, 0.0, 1.2)); dv = np.array((0.0, 1.0, 0.0))
-    rows = []
-    for j in range(nv + 1):
-        row = []
-        for i in range(nu + 1):
-            s, t = i / nu, j / nv
-            bump = 0.03 * math.sin(40 * s) * math.cos(34 * t) + 0.02 * math.sin(91 * s + 57 * t)
-            p = o + du * s + dv * t + np.array((0.06 + bump, 0, 0))
-            nx = np.array((1.0, -0.03 * 34 * -math.sin(40 * s) * math.sin(34 * t), -0.03 * 40 * math.cos(40 * s) * math.cos(34 * t)))
-            nx /= np.linalg.norm(nx)
-            row.append(m.add_vertex(p, nx, (s * 2, t * 2)))
-        rows.append(row)
-    for j in range(nv):
-        for i in range(nu):
-            a, b, c, d = rows[j][i], rows[j][i + 1], rows[j + 1][i + 1], rows[j + 1][i]
-            m.add_tri(a, b, c, TOWEL); m.add_tri(a, c, d, TOWEL)
+    sv = [i / nu for i in range(nu + 1)]; tv = [j / nv for j in range(nv + 1)]
+    s40 = np.array([math.sin(40 * x) for x in sv])[None, :]; c40 = np.array([math.cos(40 * x) for x in sv])[None, :]
+    s34 = np.array([math.sin(34 * x) for x in tv])[:, None]; c34 = np.array([math.cos(34 * x) for x in tv])[:, None]
+    S, T = np.meshgrid(np.array(sv), np.array(tv))                                     # [j, i]
+    arg = 91 * S + 57 * T
+    s91 = np.array([math.sin(x) for x in arg.ravel().tolist()]).reshape(arg.shape)     # (libm's sin, like the per-vertex loop this replaces)
+    bump = 0.03 * s40 * c34 + 0.02 * s91
+    p = ((o[None, None, :] + du[None, None, :] * S[..., None]) + dv[None, None, :] * T[..., None]) + np.stack([0.06 + bump, np.zeros_like(bump), np.zeros_like(bump)], -1)
+    nx = np.stack(np.broadcast_arrays(np.ones_like(bump), (-0.03 * 34 * -s40) * s34, (-0.03 * 40 * c40) * c34), -1)
+    nx = nx / np.sqrt((nx[..., 0] * nx[..., 0] + nx[..., 1] * nx[..., 1]) + nx[..., 2] * nx[..., 2])[..., None]
+    m.add_lattice(p, nx, np.stack([S * 2, T * 2], -1), TOWEL)
     cam = _qcam((2.0, 1.5, 4.7), (1.8, 1.1, 0.0), (0, 1, 0), 55.0, width, height)
     return m.finish("bathroom2", mats, cam, {"kind": "S-bath", "detail": detail})
 
