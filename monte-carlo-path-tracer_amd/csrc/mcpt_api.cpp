@@ -266,11 +266,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
                                   (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
                                   (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o, (void**)&L.pool.block_items};
                 for (int i = 0; i < 13; i++) {
-                    // the shadow-ray records live behind the extend-ray records in ONE allocation (sq_o = ray_o + P, sq_d = ray_d + P): the
-                    // trace kernel's refill reads either kind through one uniform base + a per-lane 32-bit index
-                    if (i == 3 || i == 11) { *dst[i] = static_cast<char*>(L.pool_bufs[i == 3 ? 1 : 0].p) + size_t(P) * 16; continue; }
-                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : i == 12 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint2)
-                                       : i <= 1 ? size_t(P) * 32 : size_t(P) * 16;
+                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : i == 12 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint2) : size_t(P) * 16;
                     if ((e = L.pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
                     if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
                     *dst[i] = L.pool_bufs[i].p;

@@ -900,7 +900,6 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 #endif
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = pool.P;
-    const uint32_t sq_off = (uint32_t)(pool.sq_o - pool.ray_o);      // one allocation (mcpt_api.cpp); also sq_d - ray_d
     // the ray list and its chunks: exactly as in wf_trace_kernel
     const uint32_t n_ext_chunks = P / WF_SHADE_BLOCK;
     const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
@@ -952,8 +951,8 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     const bool speculate = tune.pend_cap != 0u;      // MCPT_WF_PEND=0 (developer knob): a lane with a parked leaf group waits for the leaf block
     const bool greedy = tune.policy == 1;
 
-    // One inner step in two halves, so that the refill block can put its own loads between them (see there): `issue` picks the next child of
-    // the group on top of the stack and requests its record, `consume` tests the eight boxes and updates the stack.
+    // One inner step in two halves: `issue` picks the next child of the group on top of the stack and requests its record, `consume` tests the
+    // eight boxes and updates the stack.
     v4f R0, R1, R2, R3, R4;
     bool order_matters = true;
     auto inner_issue = [&]() __attribute__((always_inline)) {
@@ -1036,16 +1035,15 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 }
                 have = false;
             }
-            // New rays for the idle lanes -- with an inner step of the busy lanes INSIDE the round trip.  The ray records stream from HBM
-            // (~6 000 cycles per refill, 30 % of a wave's time) and vector-memory results return in issue order, so the only work that can
-            // overlap them is work whose own loads were requested first: the busy lanes pick their next node and request its record, THEN the
-            // ray records are requested, then the boxes are tested while the rays are still in flight.  For the compiler to wait for the node
-            // records only (s_waitcnt vmcnt(3)) the three ray loads are unconditional: a lane without a new ray reads entry 0.
-            bool got = false, my_shadow = false; uint32_t my_w = 0, my_q = 0;
+            // (Tried in round 3 and dropped: an inner step of the busy lanes INSIDE this block's memory round trip -- node records requested
+            // before the ray records, boxes tested while the rays are in flight, `s_waitcnt vmcnt(3)`.  The wait worked; the step did not pay:
+            // it runs with the ~25 lanes that are busy at a refill, i.e. it ADDS low-occupancy box-test issues to a pipeline that is bound by
+            // VALU issue, and the node + ray records in flight together cost 30 registers: 234 vs 218 ms per 512 spp.)
             if (!exhausted) {
                 const uint64_t m_idle = __ballot(!have);
                 const uint32_t rank = lane_rank(m_idle);
                 uint32_t remaining = (uint32_t)__popcll(m_idle), assigned = 0;
+                bool got = false, my_shadow = false; uint32_t my_w = 0, my_q = 0;
                 for (int pass = 0; pass < 4 && remaining > 0; pass++) {
                     if (w_next == w_end) {
                         if (c_next == c_end) {
@@ -1060,49 +1058,34 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     if (!have && !got && rank >= assigned && rank < assigned + take) { got = true; my_w = w_next + (rank - assigned); my_shadow = chunk_shadow; my_q = q_base; }
                     w_next += take; assigned += take; remaining -= take;
                 }
-            }
-            order_matters = __ballot(have && !any) != 0;
-            const bool step = have && (cur_y & 0xffu) != 0u && (speculate || t_y == 0u);
-#ifndef WF8_NO_FUSED_REFILL
-            if (step) inner_issue();
-#endif
-            const uint32_t iq = my_shadow ? my_q + my_w : 0u, ia = got ? (my_shadow ? sq_off + iq : my_w) : 0u;   // (shadow records follow the extend records: sq_o = ray_o + sq_off)
-            const float4 ro = ld_s(pool.ray_o + ia);
-            const float4 rd = ld_s(pool.ray_d + ia);
-            const uint32_t qs = ld_s(pool.shadow_queue + iq);
-#ifndef WF8_NO_FUSED_REFILL
-            if (step) {
-                inner_consume();
-#ifdef WF_SCHED_STATS
-                n_box++;
-#endif
-            }
-#endif
-            if (got) {
-                bool valid;
-                o = xyz(ro); d = xyz(rd);
-                if (!my_shadow) {                                        // extend ray of slot my_w
-                    slot = my_w;
-                    valid = (__float_as_uint(rd.w) & 1u) != 0u;
-                    tmax = 3.0e38f; any = false; htri = -1;
-                } else {                                                 // queued shadow ray: origin.w = the light triangle to skip, direction.w = t2
-                    slot = qs;
-                    tmax = rd.w; any = true; htri = __float_as_int(ro.w); valid = true;
-                }
-                if (valid) {
-                    const float tiny = 1e-30f;
-                    idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
-                    idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
-                    idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
-                    // the visiting order only matters to closest-hit rays (Render.cpp:125 asks whether the light is visible at all):
-                    // any-hit rays keep octant 0, i.e. slot order -- and a wave that carries no closest-hit ray skips the permutation
-                    oct = any ? 0u : ((idx < 0.0f ? 1u : 0u) | (idy < 0.0f ? 2u : 0u) | (idz < 0.0f ? 4u : 0u));
-                    v2u bottom; bottom.x = 0u; bottom.y = 0u;
-                    stk[0] = bottom; sp = 1;
-                    cur_x = 0u; cur_y = 1u;                              // "child 0 of base 0, no inner siblings": the root
-                    t_x = 0u; t_y = 0u;
-                    hu = 0.f; hv = 0.f; blocked = false;
-                    have = true;
+                if (got) {
+                    bool valid;
+                    if (!my_shadow) {
+                        slot = my_w;
+                        const float4 rd = ld_s(&pool.ray_d[my_w]);
+                        valid = (__float_as_uint(rd.w) & 1u) != 0u;
+                        const float4 ro = ld_s(&pool.ray_o[my_w]);
+                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; htri = -1;
+                    } else {
+                        slot = ld_s(&pool.shadow_queue[my_q + my_w]);
+                        const float4 ro = ld_s(&pool.sq_o[my_q + my_w]), sd = ld_s(&pool.sq_d[my_q + my_w]);
+                        o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; htri = __float_as_int(ro.w); valid = true;
+                    }
+                    if (valid) {
+                        const float tiny = 1e-30f;
+                        idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+                        idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+                        idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+                        // the visiting order only matters to closest-hit rays (Render.cpp:125 asks whether the light is visible at all):
+                        // any-hit rays keep octant 0, i.e. slot order -- and a wave that carries no closest-hit ray skips the permutation
+                        oct = any ? 0u : ((idx < 0.0f ? 1u : 0u) | (idy < 0.0f ? 2u : 0u) | (idz < 0.0f ? 4u : 0u));
+                        v2u bottom; bottom.x = 0u; bottom.y = 0u;
+                        stk[0] = bottom; sp = 1;
+                        cur_x = 0u; cur_y = 1u;                          // "child 0 of base 0, no inner siblings": the root
+                        t_x = 0u; t_y = 0u;
+                        hu = 0.f; hv = 0.f; blocked = false;
+                        have = true;
+                    }
                 }
             }
             WF_TICK(t_refill)
