@@ -97,6 +97,11 @@ struct DevScene {
     const double* light_pos64;     // 9 doubles / light: the fp64 corners of lights[i].tri again, contiguous (no lights[i].tri -> tri_pos64 chain)
     const float4* texels;
     DevCamera cam;
+    double centre[3];              // every coordinate on the device (vertices, boxes, planes, camera eye) is RELATIVE to this point -- the fp64 centre
+                                   // of the scene's bounding box, subtracted on the host in fp64 before anything is rounded to fp32: the reference
+                                   // works in fp64 world coordinates, where its absolute ray epsilon t1 = 1e-4 (Render.h:30) is translation-invariant;
+                                   // fp32 keeps that property only while |coordinate| * 2^-24 << 1e-4.  World-space values the reference itself
+                                   // rounds to fp32 (the light point and hit point of Render::sample) get the centre added back first (sample_light).
     int32_t n_tris, n_lights, n_nodes, n_mats, n_nodes4, n_nodes8;
 };
 

@@ -314,6 +314,7 @@ __global__ void probe_cast_ray_kernel(DevScene sc, uint32_t n, const int* xy, co
     if (i >= n) return;
     f3 o, d; d3 o64;
     cast_ray(sc.cam, xy[2 * i], xy[2 * i + 1], xi[2 * i], xi[2 * i + 1], o64, o, d);
+    o = to_f3(o64 + mkd(sc.centre[0], sc.centre[1], sc.centre[2]));      // the caller's world coordinates (the device works relative to DevScene::centre)
     out6[6 * i + 0] = o.x; out6[6 * i + 1] = o.y; out6[6 * i + 2] = o.z; out6[6 * i + 3] = d.x; out6[6 * i + 4] = d.y; out6[6 * i + 5] = d.z;
 }
 

@@ -112,6 +112,13 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
     return (v && *v) ? uint32_t(std::strtoul(v, nullptr, 10)) : dflt;
 }
 
+// Probe entry points take and return WORLD coordinates; the device works relative to DevScene::centre.
+std::vector<double> to_local(const mcpt_ctx* c, const double* p, size_t n) {
+    std::vector<double> v(3 * n);
+    for (size_t i = 0; i < n; i++) for (int a = 0; a < 3; a++) v[3 * i + a] = p[3 * i + a] - c->dev.centre[a];
+    return v;
+}
+
 // scratch device buffer for probes
 // Device scratch of one probe / tonemap call.  The fills below go through the legacy default stream, the kernels that use the buffers
 // run on the context's stream, which is NON-BLOCKING (no implicit ordering with the default stream): hipMemset on device memory
@@ -291,6 +298,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
     d.lights = static_cast<const DevLight*>(c->lights.p); d.light_pos64 = static_cast<const double*>(c->light_pos64.p); d.texels = static_cast<const float4*>(c->texels.p);
     d.cam = hs.cam;
+    for (int a = 0; a < 3; a++) d.centre[a] = hs.centre[a];
     d.n_tris = int32_t(hs.tri_face.size()); d.n_lights = int32_t(hs.lights.size()); d.n_nodes = int32_t(hs.nodes.size() / 4); d.n_mats = int32_t(hs.mats.size());
 
     c->binary_ok = hs.binary_ok;
@@ -644,7 +652,8 @@ mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, co
     if (!ctx->binary_ok) return fail(MCPT_ERR_BVH_DEPTH, "the binary cross-check tree of this (device-built) scene is deeper than its kernels' stack: use mcpt_probe_trace4");
     if (n == 0) return MCPT_OK;
     Scratch s; double *d_o, *d_d, *d_t1, *d_t2; float *d_t, *d_u, *d_v; int* d_tri;
-    HIP_TRY(s.in(origin, 3 * size_t(n), &d_o)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.in(t1, n, &d_t1)); HIP_TRY(s.in(t2, n, &d_t2));
+    const std::vector<double> lo = to_local(ctx, origin, n);
+    HIP_TRY(s.in(lo.data(), 3 * size_t(n), &d_o)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.in(t1, n, &d_t1)); HIP_TRY(s.in(t2, n, &d_t2));
     HIP_TRY(s.out(n, &d_t)); HIP_TRY(s.out(n, &d_tri)); HIP_TRY(s.out(n, &d_u)); HIP_TRY(s.out(n, &d_v));
     HIP_TRY(launch_probe_trace(ctx->dev, n, d_o, d_d, d_t1, d_t2, any_hit, d_t, d_tri, d_u, d_v, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -674,7 +683,7 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
         float* o4 = &ro[4 * size_t(i)]; float* d4 = &rd[4 * size_t(i)]; float* s4 = &sd[4 * size_t(i)];
         o4[3] = no_skip_f; d4[2] = 1.f; s4[2] = 1.f;
         if (i >= n) continue;
-        for (int k = 0; k < 3; k++) { o4[k] = float(origin[3 * size_t(i) + k]); d4[k] = float(dir[3 * size_t(i) + k]); s4[k] = d4[k]; }
+        for (int k = 0; k < 3; k++) { o4[k] = float(origin[3 * size_t(i) + k] - ctx->dev.centre[k]); d4[k] = float(dir[3 * size_t(i) + k]); s4[k] = d4[k]; }
         if (any_hit) {
             s4[3] = t2[i] > 3.0e38 ? 3.0e38f : float(t2[i]);
             queue[i] = i;                                               // shade block b queues its own slots in order
@@ -751,7 +760,8 @@ mcpt_status mcpt_probe_sample_light(mcpt_ctx* ctx, uint32_t n, const double* poi
     if (!point || !xi || !out10) return fail(MCPT_ERR_INVALID_ARG, "null argument");
     if (n == 0) return MCPT_OK;
     Scratch s; double* d_p; float *d_xi, *d_out;
-    HIP_TRY(s.in(point, 3 * size_t(n), &d_p)); HIP_TRY(s.in(xi, 3 * size_t(n), &d_xi)); HIP_TRY(s.out(10 * size_t(n), &d_out));
+    const std::vector<double> lp = to_local(ctx, point, n);
+    HIP_TRY(s.in(lp.data(), 3 * size_t(n), &d_p)); HIP_TRY(s.in(xi, 3 * size_t(n), &d_xi)); HIP_TRY(s.out(10 * size_t(n), &d_out));
     HIP_TRY(launch_probe_sample_light(ctx->dev, n, d_p, d_xi, d_out, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(out10, d_out, 10 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
@@ -764,7 +774,8 @@ mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, co
     if (n == 0) return MCPT_OK;
     if (ctx->opts.integrator != MCPT_INTEGRATOR_MIS) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_paths drives the MIS integrator only");
     Scratch s; double *d_o, *d_d; float* d_out; DevCounters* d_cnt;
-    HIP_TRY(s.in(origin, 3 * size_t(n), &d_o)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.out(3 * size_t(n), &d_out)); HIP_TRY(s.out(1, &d_cnt));
+    const std::vector<double> lo = to_local(ctx, origin, n);
+    HIP_TRY(s.in(lo.data(), 3 * size_t(n), &d_o)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.out(3 * size_t(n), &d_out)); HIP_TRY(s.out(1, &d_cnt));
     RenderParams p; std::memset(&p, 0, sizeof p);
     p.spp = 1; p.first_sample = 0; p.samples_per_item = 1; p.chunks = 1; p.tiles_x = 0x7fffffffu; p.tiles_y = 1; p.tile_mod = 1; p.tile_rem = 0; p.n_owned = 0x7fffffffu;
     p.max_depth = ctx->opts.max_depth; p.flags = ctx->opts.flags & ~MCPT_FLAG_COUNT_TRAVERSAL; p.integrator = MCPT_INTEGRATOR_MIS;

@@ -95,15 +95,18 @@ struct TravCount { uint32_t box, tri; };
 // quantities in fp64 (Triangle.cpp:48-66, :83-104); the acceptance rules are the reference's, see tri_accept_*.
 struct TriTest { float a, t, u, v; };
 DEV TriTest tri_test(const float4 v0, const float4 e1, const float4 e2, const f3 o, const f3 d) {
-    const float hx = d.y * e2.z - e2.y * d.z, hy = d.z * e2.x - e2.z * d.x, hz = d.x * e2.y - e2.x * d.y;   // h = d x e2
+    // Every product-sum is spelled as an explicit fma chain (nothing is left for -ffp-contract to decide): each inlined copy (the two
+    // triangles of a leaf pair, the binary-tree kernels) then rounds identically, so a triangle's (t, u, v) do not depend on which tree
+    // or which slot of a pair it was reached through -- deterministic renders agree bit for bit across differently built trees.
+    const float hx = fmaf(d.y, e2.z, -(e2.y * d.z)), hy = fmaf(d.z, e2.x, -(e2.z * d.x)), hz = fmaf(d.x, e2.y, -(e2.x * d.y));   // h = d x e2
     TriTest r;
-    r.a = e1.x * hx + e1.y * hy + e1.z * hz;
+    r.a = fmaf(e1.z, hz, fmaf(e1.y, hy, e1.x * hx));
     const float sx = o.x - v0.x, sy = o.y - v0.y, sz = o.z - v0.z;
-    const float qx = sy * e1.z - e1.y * sz, qy = sz * e1.x - e1.z * sx, qz = sx * e1.y - e1.x * sy;         // q = s x e1
+    const float qx = fmaf(sy, e1.z, -(e1.y * sz)), qy = fmaf(sz, e1.x, -(e1.z * sx)), qz = fmaf(sx, e1.y, -(e1.x * sy));         // q = s x e1
     const float inv_a = __builtin_amdgcn_rcpf(r.a);
-    r.u = (sx * hx + sy * hy + sz * hz) * inv_a;
-    r.v = (d.x * qx + d.y * qy + d.z * qz) * inv_a;
-    r.t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv_a;
+    r.u = fmaf(sz, hz, fmaf(sy, hy, sx * hx)) * inv_a;
+    r.v = fmaf(d.z, qz, fmaf(d.y, qy, d.x * qx)) * inv_a;
+    r.t = fmaf(e2.z, qz, fmaf(e2.y, qy, e2.x * qx)) * inv_a;
     return r;
 }
 // Triangle::isIntersect (Triangle.cpp:85-104): |det| >= 1e-6, 0 <= u <= 1, v >= 0, u + v <= 1, t1 <= t <= t2 (inclusive)
@@ -113,6 +116,12 @@ DEV bool tri_accept_any(const TriTest& r, float tmin, float tmax) {
 // Triangle::hit (Triangle.cpp:54,66): |a| >= 1e-5, t1 <= t < t2, u, v, 1-u-v >= 0
 DEV bool tri_accept_closest(const TriTest& r, float tmin, float tmax) {
     return fabsf(r.a) >= 0.00001f && r.t >= tmin && r.t < tmax && r.u >= 0.0f && r.v >= 0.0f && (1.0f - r.u - r.v) >= 0.0f;
+}
+// The same rule with a defined winner among triangles at EXACTLY the same distance: the lower (leaf-order) index.  The reference lets the
+// first one in its traversal order win (t < t2 is strict, SURVEY A-4); the 8-wide kernel tests a ray's leaf groups in an order that depends
+// on when its wave ran the leaf block, so "first tested" is not a function of the ray there -- min over (t, index) is.
+DEV bool tri_accept_closest_tie(const TriTest& r, float tmin, float tmax, int tri, int best_tri) {
+    return fabsf(r.a) >= 0.00001f && r.t >= tmin && (r.t < tmax || (r.t == tmax && tri < best_tri)) && r.u >= 0.0f && r.v >= 0.0f && (1.0f - r.u - r.v) >= 0.0f;
 }
 
 template <bool ANY, bool COUNT>
@@ -368,7 +377,7 @@ DEV LightData light_fetch(const DevScene& sc, float xi_l) {
 // The light point is interpolated in fp64 and rounded to fp32 exactly like `vec3 point = light->interplote_Vertex(..)`.
 // self_hit = Triangle::isIntersect (Triangle.cpp:83-106) of the SAMPLED triangle against the shadow ray in fp64 with the
 // reference's inclusive t <= t2 = float(|d|): the rounding-level self-occlusion of SURVEY A-9.
-DEV LightSample sample_light(const LightData& ld, d3 p64, float xi_u, float xi_v, bool guard) {
+DEV LightSample sample_light(const LightData& ld, d3 p64, float xi_u, float xi_v, bool guard, d3 centre) {
     // DevLight layout: tri, area, radiance[3], n0[3], n1[3], n2[3], pad  ->  a = {tri, area, r, g}  b = {b, n0x, n0y, n0z}  c = {n1x, n1y, n1z, n2x}  e = {n2y, n2z, pad, -}
     const int ltri = __float_as_int(ld.a.x); const float area = ld.a.y;
     const f3 rad = mk3(ld.a.z, ld.a.w, ld.b.x);
@@ -377,13 +386,15 @@ DEV LightSample sample_light(const LightData& ld, d3 p64, float xi_u, float xi_v
     if (u + v > 1.f) { u = 1.f - u; v = 1.f - v; }                      // Triangle.cpp:15-22
     const d3 v0 = ld.v0, v1 = ld.v1, v2 = ld.v2;
     const double b1 = (double)u, b2 = (double)v;
-    const f3 point = to_f3((1.0 - b1 - b2) * v0 + b1 * v1 + b2 * v2);
+    // (`centre`: device coordinates are relative to DevScene::centre; the two points the reference rounds to fp32 are WORLD points, and the
+    // self-occlusion coin below hangs on the last bit of exactly those roundings -- so the centre is added back, in fp64, before them)
+    const f3 point = to_f3(((1.0 - b1 - b2) * v0 + b1 * v1 + b2 * v2) + centre);
     const float w = 1.f - u - v;
     const f3 normal = normalize(mk3(w * n0.x + u * n1.x + v * n2.x, w * n0.y + u * n1.y + v * n2.y, w * n0.z + u * n1.z + v * n2.z));
     // The next five values feed the fp64 self-hit predicate below, whose verdict hangs on their LAST BIT (SURVEY A-9): they are
     // computed with the reference's exact rounding sequence (glm: products and sums rounded one by one, (x*x + y*y) + z*z,
     // v * (1 / sqrt(dot)); Render.cpp:208-213,217): contraction is switched off for this block and sqrt / divide are IEEE.
-    const f3 po = to_f3(p64);
+    const f3 po = to_f3(p64 + centre);
     f3 d, dir; float d2, t2;
     {
 #pragma clang fp contract(off)
@@ -432,5 +443,5 @@ DEV d3 hit_point64_plane(const DevScene& sc, int tri, d3 o64, f3 dir) {
     return mkd(fma(t, dd.x, o64.x), fma(t, dd.y, o64.y), fma(t, dd.z, o64.z));
 }
 DEV LightSample sample_light(const DevScene& sc, d3 p64, float xi_l, float xi_u, float xi_v, bool guard) {
-    return sample_light(light_fetch(sc, xi_l), p64, xi_u, xi_v, guard);
+    return sample_light(light_fetch(sc, xi_l), p64, xi_u, xi_v, guard, mkd(sc.centre[0], sc.centre[1], sc.centre[2]));
 }

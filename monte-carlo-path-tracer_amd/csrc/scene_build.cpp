@@ -23,6 +23,8 @@
 #include <system_error>
 #include <thread>
 
+static constexpr double kMaxCoord = 1e18;
+
 namespace {
 
 struct BTri { double lo[3], hi[3], c[3]; };
@@ -536,8 +538,6 @@ std::string validate_bvh8(const HostScene& hs) {
     return "";
 }
 
-static constexpr double kMaxCoord = 1e18;
-
 mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh, const Collapse4Fn& custom_collapse) {
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
     if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }
@@ -571,7 +571,24 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         out.mats.push_back(dm);
     }
 
-    // ---- flatten faces (Render.cpp:12-44)
+    // ---- flatten faces (Render.cpp:12-44).  Coordinates are taken relative to the fp64 centre of the scene's bounding box (DevScene::centre):
+    // the first pass validates and finds the box, the second builds the triangle bounds in centred coordinates.
+    {
+        double lo[3] = {std::numeric_limits<double>::max(), std::numeric_limits<double>::max(), std::numeric_limits<double>::max()}, hi[3] = {-lo[0], -lo[1], -lo[2]};
+        for (uint32_t f = 0; f < nf; f++) {
+            const int32_t* c = d->face + 12 * size_t(f);
+            for (int k = 0; k < 3; k++) {
+                if (c[4 * k] < 0 || uint32_t(c[4 * k]) >= d->n_vertex) { err = "face " + std::to_string(f) + ": index out of range"; return MCPT_ERR_INVALID_ARG; }
+                for (int a = 0; a < 3; a++) { const double x = d->vertex[3 * size_t(c[4 * k]) + a]; if (x < lo[a]) lo[a] = x; if (x > hi[a]) hi[a] = x; }   // (NaN compares false: caught below)
+            }
+        }
+        const char* keep = std::getenv("MCPT_NO_RECENTRE");                // developer knob: world coordinates on the device, as in rounds 1-2
+        for (int a = 0; a < 3; a++) {
+            const double c = 0.5 * lo[a] + 0.5 * hi[a];
+            out.centre[a] = (keep && *keep == '1') || !(std::fabs(c) <= kMaxCoord) ? 0.0 : c;
+        }
+    }
+    const double* const ctr = out.centre;
     std::vector<BTri> bt(nf);
     for (uint32_t f = 0; f < nf; f++) {
         const int32_t* c = d->face + 12 * size_t(f);
@@ -582,9 +599,10 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         if (c[3] < 0 || uint32_t(c[3]) >= d->n_materials) { err = "face " + std::to_string(f) + ": material out of range"; return MCPT_ERR_INVALID_ARG; }
         BTri& T = bt[f];
         for (int a = 0; a < 3; a++) {
-            const double x0 = d->vertex[3 * size_t(c[0]) + a], x1 = d->vertex[3 * size_t(c[4]) + a], x2 = d->vertex[3 * size_t(c[8]) + a];
+            const double w0 = d->vertex[3 * size_t(c[0]) + a], w1 = d->vertex[3 * size_t(c[4]) + a], w2 = d->vertex[3 * size_t(c[8]) + a];
+            const double x0 = w0 - ctr[a], x1 = w1 - ctr[a], x2 = w2 - ctr[a];
             // NaN / inf coordinates have no order (the builders' partitions need one) and anything past 1e18 overflows the fp32 boxes' areas
-            if (!(std::fabs(x0) <= kMaxCoord && std::fabs(x1) <= kMaxCoord && std::fabs(x2) <= kMaxCoord)) {
+            if (!(std::fabs(w0) <= kMaxCoord && std::fabs(w1) <= kMaxCoord && std::fabs(w2) <= kMaxCoord)) {
                 err = "face " + std::to_string(f) + ": vertex coordinate is not finite or exceeds 1e18"; return MCPT_ERR_INVALID_ARG;
             }
             T.lo[a] = std::min(x0, std::min(x1, x2)); T.hi[a] = std::max(x0, std::max(x1, x2));
@@ -663,14 +681,15 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     for (uint32_t i = i_begin; i < i_end; i++) {
         const int f = order[i];
         const int32_t* c = d->face + 12 * size_t(f);
-        const double* v0 = d->vertex + 3 * size_t(c[0]); const double* v1 = d->vertex + 3 * size_t(c[4]); const double* v2 = d->vertex + 3 * size_t(c[8]);
+        const double* w0 = d->vertex + 3 * size_t(c[0]); const double* w1 = d->vertex + 3 * size_t(c[4]); const double* w2 = d->vertex + 3 * size_t(c[8]);
+        const double v0[3] = {w0[0] - ctr[0], w0[1] - ctr[1], w0[2] - ctr[2]}, v1[3] = {w1[0] - ctr[0], w1[1] - ctr[1], w1[2] - ctr[2]}, v2[3] = {w2[0] - ctr[0], w2[1] - ctr[1], w2[2] - ctr[2]};
         const double* n0 = d->normal + 3 * size_t(c[1]); const double* n1 = d->normal + 3 * size_t(c[5]); const double* n2 = d->normal + 3 * size_t(c[9]);
         const double* t0_ = d->texcoord + 2 * size_t(c[2]); const double* t1_ = d->texcoord + 2 * size_t(c[6]); const double* t2_ = d->texcoord + 2 * size_t(c[10]);
         const uint32_t mflags = out.mats[size_t(c[3])].flags;
         const uint32_t lobe_class = !(mflags & MAT_HAS_SPEC) ? HIT_CLASS_DIFFUSE : (mflags & MAT_MIRROR) ? HIT_CLASS_MIRROR : HIT_CLASS_PHONG;
         out.tri_isect[3 * size_t(i) + 0] = {float(v0[0]), float(v0[1]), float(v0[2]), as_float(int(lobe_class << HIT_CLASS_SHIFT))};
-        out.tri_isect[3 * size_t(i) + 1] = {float(v1[0] - v0[0]), float(v1[1] - v0[1]), float(v1[2] - v0[2]), 0.f};
-        out.tri_isect[3 * size_t(i) + 2] = {float(v2[0] - v0[0]), float(v2[1] - v0[1]), float(v2[2] - v0[2]), 0.f};
+        out.tri_isect[3 * size_t(i) + 1] = {float(w1[0] - w0[0]), float(w1[1] - w0[1]), float(w1[2] - w0[2]), 0.f};      // (edges from the world coordinates: Triangle.cpp:25-26's values)
+        out.tri_isect[3 * size_t(i) + 2] = {float(w2[0] - w0[0]), float(w2[1] - w0[1]), float(w2[2] - w0[2]), 0.f};
         out.tri_shade[4 * size_t(i) + 0] = {float(n0[0]), float(n0[1]), float(n0[2]), float(t0_[0])};
         out.tri_shade[4 * size_t(i) + 1] = {float(n1[0]), float(n1[1]), float(n1[2]), float(t0_[1])};
         out.tri_shade[4 * size_t(i) + 2] = {float(n2[0]), float(n2[1]), float(n2[2]), float(t1_[0])};
@@ -713,7 +732,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     cam.h = std::tan(cm.fovy * PI_D / 180.0 * 0.5) * 2.0;
     double fr[3] = {cm.lookat[0] - cm.eye[0], cm.lookat[1] - cm.eye[1], cm.lookat[2] - cm.eye[2]};
     double inv = 1.0 / len3(fr);
-    for (int a = 0; a < 3; a++) { cam.front[a] = fr[a] * inv; cam.eye[a] = cm.eye[a]; cam.up[a] = cm.up[a]; }
+    for (int a = 0; a < 3; a++) { cam.front[a] = fr[a] * inv; cam.eye[a] = cm.eye[a] - ctr[a]; cam.up[a] = cm.up[a]; }   // (front from the world coordinates, like Render.cpp:74)
     double rt[3] = {cam.front[1] * cm.up[2] - cm.up[1] * cam.front[2], cam.front[2] * cm.up[0] - cm.up[2] * cam.front[0],
                     cam.front[0] * cm.up[1] - cm.up[0] * cam.front[1]};
     inv = 1.0 / len3(rt);

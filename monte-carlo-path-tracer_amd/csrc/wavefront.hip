@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
                 const double* LP = s_light_pos + 9 * li;
                 ld.v0 = mkd(LP[0], LP[1], LP[2]); ld.v1 = mkd(LP[3], LP[4], LP[5]); ld.v2 = mkd(LP[6], LP[7], LP[8]);
             } else ld = light_fetch(sc, ra.v[0]);
-            ls = sample_light(ld, p64, ra.v[1], ra.v[2], true);
+            ls = sample_light(ld, p64, ra.v[1], ra.v[2], true, mkd(sc.centre[0], sc.centre[1], sc.centre[2]));
         }
         WF_PHASE();
         SH_TICK(2)                                                                                // phase 2: fp64 hit point + light sample
@@ -1120,12 +1120,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     if (use_a) {
                         const TriTest r = tri_test(v0a, e1a, e2a, o, d);
                         if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }                     // Triangle::isIntersect
-                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ta | __float_as_int(v0a.w); hu = r.u; hv = r.v; }   // Triangle::hit; v0.w = lobe class << 28
+                        else if (tri_accept_closest_tie(r, 1e-4f, tmax, ta, htri & HIT_TRI_MASK)) { tmax = r.t; htri = ta | __float_as_int(v0a.w); hu = r.u; hv = r.v; }   // Triangle::hit; v0.w = lobe class << 28
                     }
                     if (use_b && !done) {
                         const TriTest r = tri_test(v0b, e1b, e2b, o, d);
                         if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }
-                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = tb | __float_as_int(v0b.w); hu = r.u; hv = r.v; }
+                        else if (tri_accept_closest_tie(r, 1e-4f, tmax, tb, htri & HIT_TRI_MASK)) { tmax = r.t; htri = tb | __float_as_int(v0b.w); hu = r.u; hv = r.v; }
                     }
                 }
                 if (done) { cur_y = 0u; t_y = 0u; }                      // any-hit: stop at the first occluder
