@@ -134,6 +134,10 @@ def main():
     ap.add_argument("--shard", choices=["samples", "tiles"], default="samples",
                     help="N > 1: each rank renders its own sample range of every pixel (default; weak scaling) or its interleaved share of the "
                          "8x8 pixel tiles for all samples (BASELINE.json's 'pixel-tile shard'; strong scaling: the job is fixed)")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="N",
+                    help="one GPU renders rank 0's share of an N-way STRONG-scaled split of the config's job (--shard samples: spp/N samples of every "
+                         "pixel; --shard tiles: all samples of every N-th 8x8 tile): per-rank time of an N-GPU run without the N GPUs "
+                         "(tools/scaling_emulation.py turns the sweep into profiles/r03_scaling_emulation.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--dry", action="store_true", help="launcher / collective rehearsal without a GPU: no rendering, films are synthetic")
@@ -209,10 +213,16 @@ def main():
     side = torch.cuda.Stream(device=dev)
     r.set_torch_stream(side)
 
+    emu = args.emulate_world if world == 1 else 0
+    if emu > 1 and args.shard == "samples":
+        spp = max(1, spp // emu)            # rank 0's share of the job's samples
+
     def step(s):                            # one step = one complete render job: clear the film, render this rank's sample range, sum the films
         with torch.cuda.stream(side):
             accum.zero_()
-            if args.shard == "tiles":
+            if emu > 1 and args.shard == "tiles":
+                r.render_tiles(spp, 20251004, s * spp, emu, 0)
+            elif args.shard == "tiles":
                 r.render_tiles(spp, 20251004, s * spp, *mg.tile_shard(rank, world))
             else:
                 r.render(spp, seed=20251004, first_sample=mg.first_sample(s, rank, world, spp))
@@ -235,7 +245,11 @@ def main():
     dt = time.perf_counter() - t0
     c = r.counters()
     want_count = float(spp if args.shard == "tiles" else spp * n_ranks)
-    film_ok = bool((accum.view(-1, 4)[:, 3] == want_count).all().item())   # every pixel got all the samples of the last step, from every rank
+    if emu > 1 and args.shard == "tiles":   # rank 0 of an emulated split owns every emu-th tile only
+        cnt = accum.view(H, W, 4)[:, :, 3]
+        film_ok = bool(((cnt == 0) | (cnt == float(spp))).all().item()) and abs(float((cnt > 0).float().mean().item()) - 1.0 / emu) < 0.02
+    else:
+        film_ok = bool((accum.view(-1, 4)[:, 3] == want_count).all().item())   # every pixel got all the samples of the last step, from every rank
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays = torch.tensor([float(c.rays)], dtype=torch.float64, device=dev)
     paths = torch.tensor([float(c.paths)], dtype=torch.float64, device=dev)
@@ -307,6 +321,7 @@ def main():
                               "so mpath_per_s is the like-for-like pair" % (total_rays / max(1.0, total_paths), rpp_ref),
             "self_shadow_rate": round(c.self_shadow_hits / max(1, c.self_shadow_tests), 4),
             "film_count_plane_ok": film_ok,
+            "emulated_world": emu if emu > 1 else None,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

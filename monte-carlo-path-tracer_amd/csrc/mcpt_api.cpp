@@ -58,6 +58,8 @@ struct mcpt_ctx {
     hipEvent_t fork_ev = nullptr;
     WaveTuning tune{};
     uint32_t trace_grid = 0;
+    uint32_t pool_cap = 1u << 23;       // most slots a sub-pipeline's pool may have (MCPT_WF_POOL_LOG2); pools are allocated on first use, sized to the job
+    uint32_t items_per_slot = 1;        // pool sizing knob: a job of n work items gets n / items_per_slot slots, at most pool_cap (MCPT_WF_ITEMS_PER_SLOT), see render_wavefront
     int n_cus = 0;
     uint32_t time_kernels = 0;          // MCPT_TIME_KERNELS=N: bracket the two kernels of every Nth iteration with HIP events (0 = off)
     double last_trace_ms = 0.0, total_trace_ms = 0.0, last_shade_ms = 0.0, total_shade_ms = 0.0;
@@ -241,8 +243,9 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         c->n_cus = prop.multiProcessorCount;
         const char* pipe = std::getenv("MCPT_PIPELINE");
         c->use_wavefront = !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS;
-        uint32_t P = 1u << env_u32("MCPT_WF_POOL_LOG2", 23);
-        if (P < 2048) P = 2048;
+        c->pool_cap = 1u << std::min(26u, env_u32("MCPT_WF_POOL_LOG2", 23));
+        if (c->pool_cap < 2048) c->pool_cap = 2048;
+        c->items_per_slot = std::max(1u, env_u32("MCPT_WF_ITEMS_PER_SLOT", 1));
         c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
         c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0); c->tune.pend_cap = 48;      // speculative traversal: refined below once the scene's size is known
         c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0);
@@ -267,17 +270,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             if ((e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
             c->lanes.resize(n_lanes);
             for (auto& L : c->lanes) {
-                L.pool.P = P;
-                L.pool_bufs.resize(13);
-                void** dst[13] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sq_d, (void**)&L.pool.nee,
-                                  (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
-                                  (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o, (void**)&L.pool.block_items};
-                for (int i = 0; i < 13; i++) {
-                    const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : i == 12 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint2) : size_t(P) * 16;
-                    if ((e = L.pool_bufs[i].alloc(bytes)) != hipSuccess) return bail(e, "alloc path pool");
-                    if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) return bail(e, "clear path pool");
-                    *dst[i] = L.pool_bufs[i].p;
-                }
+                L.pool.P = 0;                                             // allocated by ensure_pool() when the first job arrives
                 if ((e = L.ctl_buf.alloc(sizeof(IterCtl))) != hipSuccess) return bail(e, "alloc IterCtl");
                 if ((e = hipHostMalloc((void**)&L.h_ctl, 8 * sizeof(IterCtl), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
                 L.chk_ev.resize(8);
@@ -307,7 +300,6 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
     in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes + c->mats.bytes +
                       c->lights.bytes + c->light_pos64.bytes + c->texels.bytes + accum_bytes;
-    for (auto& L : c->lanes) for (auto& b : L.pool_bufs) in.device_bytes += b.bytes;
     in.bvh_build_ms = hs.bvh_build_ms;
     in.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out_ctx = c;
@@ -357,6 +349,29 @@ static mcpt_status resolve_timing(mcpt_ctx* c) {
     return MCPT_OK;
 }
 
+// A sub-pipeline's path pool, allocated on first use and grown (never shrunk) to the largest job seen: a 48 x 48 film gets a few hundred KB,
+// the 1024-spp bench job its 2^23 slots (1.4 GB per sub-pipeline).  All slot state is dead between render calls, so growing loses nothing.
+static mcpt_status ensure_pool(mcpt_ctx* ctx, mcpt_ctx::WfLane& L, uint32_t P) {
+    if (L.pool.P >= P) return MCPT_OK;
+    HIP_TRY(hipStreamSynchronize(L.stream)); HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto& b : L.pool_bufs) { ctx->info.device_bytes -= b.bytes; b.free_(); }
+    L.pool_bufs.clear(); L.pool_bufs.resize(13);
+    void** dst[13] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sq_d, (void**)&L.pool.nee,
+                      (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
+                      (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o, (void**)&L.pool.block_items};
+    for (int i = 0; i < 13; i++) {
+        const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : i == 12 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint2) : size_t(P) * 16;
+        hipError_t e = L.pool_bufs[i].alloc(bytes);
+        if (e != hipSuccess) { L.pool.P = 0; return hip_fail(e, "alloc path pool"); }
+        if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) { L.pool.P = 0; return hip_fail(e, "clear path pool"); }
+        *dst[i] = L.pool_bufs[i].p;
+        ctx->info.device_bytes += bytes;
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));                              // (the fills ran on the default stream)
+    L.pool.P = P;
+    return MCPT_OK;
+}
+
 static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* accum) {
     // One mcpt_render call = per sub-pipeline a loop of [shade, trace] launches over its slot pool until its work items are done.
     // The sample range is split contiguously over the sub-pipelines; their streams fork from and join the context's stream.
@@ -382,16 +397,28 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             r.p.tile_mod = p0.tile_mod * n_lanes; r.p.tile_rem = p0.tile_rem + k * p0.tile_mod;
             my_tiles = (tiles - k + n_lanes - 1) / n_lanes; r.p.n_owned = uint32_t(my_tiles);
         } else {
-            const uint32_t lo = uint32_t(uint64_t(p0.spp) * k / n_lanes), hi = uint32_t(uint64_t(p0.spp) * (k + 1) / n_lanes);
+            const uint32_t lo = uint32_t(uint64_t(p0.spp) * k / n_lanes), hi = uint32_t(uint64_t(p0.spp) * (k + 1) / n_lanes);   // (equal shares: 40 / 60 and 35 / 65 splits, so that the two pools do not drain together, were 6 - 10 % slower)
             if (hi == lo) { r.done = true; ctx->lanes[k].last_iterations = 0; continue; }
             r.p.spp = hi - lo; r.p.first_sample = p0.first_sample + lo;
         }
         if (r.p.samples_per_item > r.p.spp) r.p.samples_per_item = r.p.spp;
         r.p.chunks = (r.p.spp + r.p.samples_per_item - 1) / r.p.samples_per_item;
         r.n_items = p0.probe_n ? p0.probe_n : uint32_t(my_tiles * 64 * r.p.chunks);
-        r.pool = ctx->lanes[k].pool;
-        const uint32_t want = uint32_t(((uint64_t(r.n_items) + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK) * WF_SHADE_BLOCK);
-        if (r.pool.P > want) r.pool.P = want;                              // small jobs: do not sweep idle slots
+        // Pool slots for this job.  Up to 2^20 items: one slot each (every path starts in iteration 0).  Beyond: ~items / 16 slots, at most
+        // pool_cap.  What a slot costs is the end-of-job drain -- the last ~8 iterations sweep a pool that is emptying -- i.e. ~8 P
+        // slot-iterations on top of the ~7 n the n paths need: 3 % at the 1024-spp bench job's 40 items per slot, but 23 % for the 128-spp
+        // share of an 8-way strong-scaled split if it kept the full 2^23 slots.  Fewer than ~2^20 slots stop filling the chip.
+        {
+            const uint64_t want64 = ((uint64_t(r.n_items) + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK) * WF_SHADE_BLOCK;
+            uint64_t P = std::min<uint64_t>(want64, ctx->pool_cap);
+            if (want64 > (1ull << 20)) {
+                const uint64_t by_items = (uint64_t(r.n_items) / ctx->items_per_slot) & ~uint64_t(16 * WF_SHADE_BLOCK - 1);
+                P = std::min<uint64_t>(P, std::max<uint64_t>(by_items, 1ull << 20));
+            }
+            mcpt_status ps = ensure_pool(ctx, ctx->lanes[k], uint32_t(P)); if (ps != MCPT_OK) return ps;
+            r.pool = ctx->lanes[k].pool;
+            r.pool.P = uint32_t(P);                                        // (a smaller job sweeps only the slots it needs)
+        }
         // Every item has a slot of its own and one sample: all paths start in iteration 0, vertex b is shaded in iteration b + 1, the
         // depth limit ends the path by iteration max_depth + 1 and a parked NEE term (SLOT_DRAIN) costs one more.  The loop then runs
         // exactly that many iterations before it looks at the control block for the first time -- no launches past the end of the job.
@@ -518,7 +545,7 @@ mcpt_status mcpt_render_tiles(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32
             // atomics at once, or (b) the item count would overflow the cursor range.  Short items keep the end-of-render drain
             // short (a slot works its item off sample after sample: 8-sample items cost 2.7 % at 1024 spp on the bench workload)
             // and cost nothing any more now that items come from sharded cursors with one atomic per block.
-            const uint64_t slots = uint64_t(ctx->lanes[0].pool.P) * ctx->lanes.size(), pixels = tiles * 64;   // the pixels this call owns
+            const uint64_t slots = uint64_t(ctx->pool_cap) * ctx->lanes.size(), pixels = tiles * 64;   // the pixels this call owns
             spi = 1;
             while (spi < 64 && slots > pixels * 32ull * spi) spi <<= 1;
             while (tiles * ((spp + spi - 1) / spi) > 0x3ffffffull && spi < spp) spi <<= 1;
@@ -672,9 +699,10 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
     if (!ctx->use_wavefront || ctx->lanes.empty()) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_trace4 needs the wavefront pipeline (MIS integrator)");
     if (n == 0) return MCPT_OK;
     mcpt_ctx::WfLane& L = ctx->lanes[0];
-    PathPool pool = L.pool;
     const uint32_t P = uint32_t(((uint64_t(n) + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK) * WF_SHADE_BLOCK);
-    if (P > pool.P) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_trace4: more rays than pool slots");
+    if (P > ctx->pool_cap) return fail(MCPT_ERR_UNSUPPORTED, "mcpt_probe_trace4: more rays than pool slots");
+    st = ensure_pool(ctx, L, P); if (st != MCPT_OK) return st;
+    PathPool pool = L.pool;
     pool.P = P;
     std::vector<float> ro(4 * size_t(P), 0.f), rd(4 * size_t(P), 0.f), sd(4 * size_t(P), 0.f), hit(4 * size_t(P), 0.f);
     std::vector<uint32_t> queue(P, 0u), qcount(P / WF_SHADE_BLOCK, 0u);
@@ -698,6 +726,7 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
     HIP_TRY(hipMemcpy(pool.shadow_queue, queue.data(), queue.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pool.shadow_count, qcount.data(), qcount.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(L.ctl_buf.p, 0, sizeof(IterCtl)));
+    { const uint32_t one = 1u; HIP_TRY(hipMemcpy(&static_cast<IterCtl*>(L.ctl_buf.p)->any_active[0], &one, 4, hipMemcpyHostToDevice)); }   // "iteration 0 left live slots": the trace kernel returns at once otherwise
     HIP_TRY(hipStreamSynchronize(nullptr));                          // the fills above ran on the default stream; the kernel below does not wait for it by itself
     const bool count = (ctx->opts.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0;
     HIP_TRY(launch_wf_trace(ctx->dev, pool, static_cast<IterCtl*>(L.ctl_buf.p), 0u, ctx->tune, count, static_cast<DevCounters*>(ctx->counters.p), ctx->trace_grid,

@@ -95,8 +95,13 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
 #define SH_TICK(I)
 #endif
     if (base + tid == 0) { const uint32_t n = (it + 1) & 3; ctl->trace_head[n] = 0; ctl->any_active[n] = 0; }
+    // The host notices the end of a job a few iterations late (it polls control-block snapshots and runs up to 8 iterations ahead): once an
+    // iteration has left no live slot -- a dead slot takes the next work item in the same call, so that also means no item is left -- every
+    // later launch of the job ends here, before it streams the pool.  (An empty iteration used to cost 0.5 - 0.65 ms in this kernel and
+    // 0.2 - 0.4 ms in the trace kernel: ~10 % of a 128-spp share of a strong-scaled job.)
+    if (it != 0u && ctl->any_active[(it - 1u) & 3u] == 0u) return;
     __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64];
-    __shared__ uint32_t s_base, s_sel, s_priv_base, s_priv_take, s_priv_next, s_priv_end;
+    __shared__ uint32_t s_base, s_sel, s_scan, s_priv_base, s_priv_take, s_priv_next, s_priv_end;
     // the whole slot state of the block's 256-slot window, fetched coalesced in ONE batch by the slots' own lanes and handed to the
     // lanes that will process them through LDS: no dependent second round of (gathering) global loads after the sort ...
     __shared__ float4 s_beta[WF_SHADE_BLOCK], s_hit[WF_SHADE_BLOCK], s_L[WF_SHADE_BLOCK], s_rd[WF_SHADE_BLOCK], s_nee[WF_SHADE_BLOCK], s_ro[WF_SHADE_BLOCK];
@@ -357,9 +362,18 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
                     }
                 }
             }
+            s_scan = (rest && b0 == 0xffffffffu) ? 1u : 0u;
             s_base = b0; s_sel = sel;
         }
         __syncthreads();
+        // Slots stay empty although items may be left in shards this call did not probe: say so, or the launches after this one would take
+        // "no live slot" for "job finished" (the early return at the top of both kernels).  Only reached at the end of a job; wave 0 looks
+        // at all 64 cursors at once.
+        static_assert(WF_ITEM_SHARDS == 64, "one lane of wave 0 per work-item cursor");
+        if (wv == 0 && s_scan) {
+            const bool left = __hip_atomic_load(&ctl->item_cursor[lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wf_shard_capacity(n_items, lane);
+            if (__ballot(left) != 0 && lane == 0) ctl->any_active[it & 3u] = 1u;
+        }
         if (want_item) {
             id.z = id.w = 0; id_dirty = true;
             uint32_t before = 0;
@@ -498,6 +512,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
                                                                   int* __restrict__ stack_overflow) {
+    if (ctl->any_active[it & 3u] == 0u) return;                       // no live slot after this iteration's shade call: no ray to trace (see wf_shade_kernel)
     __shared__ int s_stack[WF_LDS_STACK * WF_TRACE_BLOCK];
     __shared__ float4 s_top[4 * MCPT_TOP_NODES];                      // [quarter][node]
     // explicit address spaces: with generic pointers hipcc folds `lds ? : global` into ONE flat_load (select of pointers), which is
@@ -875,6 +890,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
                                                                    int* __restrict__ stack_overflow) {
+    if (ctl->any_active[it & 3u] == 0u) return;                       // no live slot after this iteration's shade call: no ray to trace (see wf_shade_kernel)
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ v2u s_stack[WF8_LDS_STACK * WF_TRACE_BLOCK];
