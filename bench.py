@@ -39,9 +39,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0            # aggregate L2 bandwidth (same guide): the relevant ceiling while the scene is cache-resident
-CACHE_RESIDENT_BYTES = 16 << 20  # traversal data (4-wide nodes + triangle records) up to this size stays in L2 / Infinity Cache
+CACHE_RESIDENT_BYTES = 16 << 20  # traversal data (8-wide nodes + triangle records) up to this size stays in L2 / Infinity Cache
 # algorithmic bytes per unit of work with THIS build's layouts
-B_BOX, B_TRI = 16, 48            # a quarter of a 64-B four-child node per slab test; one 48-B {v0,e1,e2} record per triangle test
+B_BOX, B_TRI = 10, 48            # an eighth of an 80-B eight-child node per child-box test; one 48-B {v0,e1,e2} record per triangle test
 B_RAY = 32 + 16                  # trace kernel: ray fetch (origin + direction records) + 16-B result write-back per ray
 
 CONFIGS = {
@@ -72,14 +72,46 @@ def launch_ranks(n: int, argv) -> int:
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "MCPT_BENCH_SELF_LAUNCHED": "1"})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    # wait for all of them; a rank that dies (before or at the rendezvous, say) takes the others with it instead of leaving them blocked in
+    # init_process_group, and the whole launch is bounded
+    deadline = time.time() + float(os.environ.get("MCPT_BENCH_LAUNCH_TIMEOUT", "3000"))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    while procs:
+        alive = []
+        for p in procs:
+            r = p.poll()
+            if r is None: alive.append(p)
+            else: rc = max(rc, abs(r))
+        procs = alive
+        if procs and (rc != 0 or time.time() > deadline):
+            for p in procs: p.terminate()
+            for p in procs:
+                try: p.wait(timeout=20)
+                except subprocess.TimeoutExpired: p.kill()
+            return rc or 124
+        time.sleep(0.2)
     return rc
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"): return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def omp_threads(n):
+    """Thread count of the OpenMP runtime the reference / oracle libraries already loaded (libgomp is one per process)."""
+    import ctypes
+    try: ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError: pass
+
+
 def cpu_baseline(pkg, cfg, scene, rays_per_path_ref, budget_s=20.0):
-    """Time the reference's Render::render on the host cores over a bounded sample of the same workload."""
+    """Time the reference's Render::render on the host cores over a bounded sample of the same workload: all cores of the job's share,
+    then one thread (SURVEY section 8d asks for both, with core count and CPU model)."""
     # the GPU box exposes every host core in the affinity mask but a 1-GPU job's CPU share is 16 cores; the reference's
     # OpenMP loop also serialises on one shared mt19937 (utils.h:23-28), so more threads than that only add contention
     ncores = min(16, len(os.sched_getaffinity(0)))
@@ -107,7 +139,12 @@ def cpu_baseline(pkg, cfg, scene, rays_per_path_ref, budget_s=20.0):
         frames = max(1, min(64, int(budget_s / max(t1, 1e-3)) - 1))
         t = ref.render(frames)
         paths = frames * W * H
-        return {"value": round(paths * rays_per_path_ref / t / 1e6, 4), "unit": "Mray/s", "cores": ncores, "kind": "reference",
+        omp_threads(1)
+        f1 = max(1, min(frames, int(6.0 / max(t1 * ncores / 4.0, 1e-3))))       # ~6 s of single-thread work (the loop scales ~4x on 16 threads, not 16x)
+        tt1 = ref.render(f1)
+        omp_threads(ncores)
+        return {"value": round(paths * rays_per_path_ref / t / 1e6, 4), "unit": "Mray/s", "cores": ncores, "kind": "reference", "cpu_model": cpu_model(),
+                "threads_1": {"value": round(f1 * W * H * rays_per_path_ref / tt1 / 1e6, 4), "mpath_per_s": round(f1 * W * H / tt1 / 1e6, 4), "frames": f1, "seconds": round(tt1, 2)},
                 "sample": "%d frame(s) (=spp) of %dx%d %s depth %d through the real reference's Render::render (OpenMP, %d threads, "
                           "%.2f s); %s" % (frames, W, H, scene.name, depth, ncores, t, note),
                 "mpath_per_s": round(paths / t / 1e6, 4)}
@@ -118,7 +155,13 @@ def cpu_baseline(pkg, cfg, scene, rays_per_path_ref, budget_s=20.0):
         spp = max(1, min(64, int(budget_s / max(t1, 1e-3))))
         _, c, t = o.render(spp, seed=2)
         rays = c["rays_primary"] + c["rays_continuation"] + c["rays_shadow"]
-        return {"value": round(rays / t / 1e6, 4), "unit": "Mray/s", "cores": ncores, "kind": "port",
+        omp_threads(1)
+        s1 = max(1, min(spp, int(6.0 / max(t1 * ncores / 8.0, 1e-3))))
+        _, c1, tt1 = o.render(s1, seed=3)
+        omp_threads(ncores)
+        rays1 = c1["rays_primary"] + c1["rays_continuation"] + c1["rays_shadow"]
+        return {"value": round(rays / t / 1e6, 4), "unit": "Mray/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model(),
+                "threads_1": {"value": round(rays1 / tt1 / 1e6, 4), "mpath_per_s": round(c1["paths"] / tt1 / 1e6, 4), "spp": s1, "seconds": round(tt1, 2)},
                 "sample": "%dx%dx%d spp of %s depth %d through oracle/mcpt_oracle.cpp (OpenMP, %d threads, %.2f s) [%s]" % (
                     w, h, spp, scene.name, depth, ncores, t, why),
                 "mpath_per_s": round(c["paths"] / t / 1e6, 4)}
@@ -189,7 +232,7 @@ def main():
         if dist is not None:
             dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         if rank == 0:
-            print(json.dumps({"metric": "Mray/s (primary+secondary), cornell-box 1024spp", "value": 0.0, "unit": "Mray/s", "dry": True,
+            print(json.dumps({"metric": "Mray/s (primary+secondary), %s %dspp" % (cfg["scene"], cfg["spp"]), "value": 0.0, "unit": "Mray/s", "dry": True,
                               "n_gpus": n_ranks, "rccl_ranks": n_ranks, "backend": args.backend, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(float(t_all.item()) / max(1, args.steps) * 1e3, 3), "count_plane_ok": ok,
                               "first_samples_rank0": seen, "config": {"workload": cfg["label"], "spp_per_step_per_gpu": spp}}), flush=True)
@@ -273,46 +316,68 @@ def main():
         trace_bytes_per_ray = trav_bytes_per_ray + B_RAY
         algo_bytes = trace_bytes_per_ray * rays_per_launch
         achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
-        scene_bytes = info.n_nodes * 64 + info.n_tris * 48          # ~ 4-wide nodes + triangle test records
+        scene_bytes = int(info.traversal_bytes)                       # wide nodes + triangle test records, from the library
         resident = scene_bytes <= CACHE_RESIDENT_BYTES
-        # ---- measured HBM traffic / lane utilisation: PMC counters cannot be read inside this process; they come from the committed
-        # rocprofv3 --pmc passes of the same workload (tools/pmc_passes.sh -> profiles/r02_traffic.json), per ray, x this run's rays/launch
+        # ---- measured HBM traffic / VALU issue / lane utilisation: PMC counters cannot be read inside this process; they come from the
+        # committed rocprofv3 --pmc passes of the same workload and build (tools/r03_profile.sh -> profiles/r03_traffic.json), per traced ray,
+        # x this run's rays per launch / rays per second
         traffic = None; traffic_source = None; pmc = {}
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tpath):
             pmc = json.load(open(tpath)).get(args.config, {})
             if pmc.get("wf_trace_kernel_hbm_bytes_per_ray"):
                 traffic = int(pmc["wf_trace_kernel_hbm_bytes_per_ray"] * rays_per_launch)
-                traffic_source = "profiles/r02_traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (not this run), bytes per ray x this run's rays per launch" % args.config
-        roofline = {"bound": "latency/issue" if resident else "hbm",
+                traffic_source = "profiles/r03_traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (not this run), bytes per ray x this run's rays per launch" % args.config
+        rays_per_s = total_rays / dt / max(1, n_ranks)                     # this GPU's share of the job's ray rate
+        hbm_measured = None
+        if pmc.get("wf_trace_kernel_hbm_bytes_per_ray") and pmc.get("wf_shade_kernel_hbm_bytes_per_ray"):
+            tb, sb = pmc["wf_trace_kernel_hbm_bytes_per_ray"], pmc["wf_shade_kernel_hbm_bytes_per_ray"]
+            hbm_measured = {"level": "step (bytes per traced ray from the PMC passes of this build x this run's rays/s per GPU)",
+                            "trace_bytes_per_ray": tb, "shade_bytes_per_ray": sb,
+                            "trace_GBps": round(tb * rays_per_s / 1e9, 1), "shade_GBps": round(sb * rays_per_s / 1e9, 1),
+                            "total_GBps": round((tb + sb) * rays_per_s / 1e9, 1), "frac_of_hbm_peak": round((tb + sb) * rays_per_s / 1e9 / HBM_PEAK_GBS, 4),
+                            "source": "profiles/r03_traffic.json[%s]" % args.config}
+        n_streams = 2 if (c.shade_ms_total > 0 and launches >= 2) else 1
+        per_stream_ms = launches / max(1, args.steps) / n_streams * (trace_ms + shade_ms)
+        frac_alg = round(achieved / HBM_PEAK_GBS, 4)
+        roofline = {"bound": "valu-issue/latency" if resident else "hbm",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": "wf_trace_kernel<false>", "kernel_ms": round(trace_ms, 4), "launches_per_step": round(launches / max(1, args.steps), 1),
+                    "frac": frac_alg, "frac_algorithmic": frac_alg,
+                    "frac_note": "ALGORITHMIC bytes of the dominant kernel / its launch time / HBM peak (the contract's definition); the bytes the "
+                                 "memory system really moved are in hbm_measured and traffic",
+                    "traffic": traffic, "traffic_source": traffic_source, "hbm_measured": hbm_measured,
+                    "kernel": "wf_trace8_kernel<false>", "kernel_ms": round(trace_ms, 4), "launches_per_step": round(launches / max(1, args.steps), 1),
                     "rays_per_launch": int(rays_per_launch),
                     "algorithmic_bytes_per_ray": round(trace_bytes_per_ray, 1),
                     "box_tests_per_ray": round(ci.box_tests / max(1, ci.rays), 2), "tri_tests_per_ray": round(ci.tri_tests / max(1, ci.rays), 2),
                     "traversal_data_bytes": int(scene_bytes), "cache_resident": resident,
                     "l2_relative": {"traversal_GBps": round(trav_bytes_per_ray * rays_per_launch / (trace_ms * 1e-3) / 1e9, 1), "l2_peak_GBps": L2_PEAK_GBS,
                                     "frac": round(trav_bytes_per_ray * rays_per_launch / (trace_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4)},
+                    "valu_issue_frac": pmc.get("valu_issue_frac"), "valu_issue_note": pmc.get("valu_issue_note"),
                     "valu_lane_utilisation": pmc.get("wf_trace_kernel_valu_lane_utilisation"),
+                    "salu_to_valu_instructions": pmc.get("wf_trace_kernel_salu_to_valu"),
+                    "inner_steps_per_ray": pmc.get("wf_trace_kernel_inner_steps_per_ray"),
                     "second_kernel": {"kernel": "wf_shade_kernel<false>", "kernel_ms": round(shade_ms, 4),
                                       "valu_lane_utilisation": pmc.get("wf_shade_kernel_valu_lane_utilisation")},
-                    "concurrency": "two sub-pipelines run concurrently (shade of one overlaps trace of the other), so per-launch durations are "
-                                   "those of kernels sharing the GPU and their sum exceeds the step time",
+                    "streams": n_streams,
+                    "per_stream_ms_per_step": round(per_stream_ms, 2),
+                    "reconciliation": "each of the %d sub-pipeline streams runs launches_per_step / %d x (trace %.4f + shade %.4f ms) = %.1f ms of "
+                                      "back-to-back kernels per step; ms_per_step = %.1f (the two streams overlap: a kernel's duration is that of a kernel "
+                                      "sharing the GPU with the other stream's)" % (n_streams, n_streams, trace_ms, shade_ms, per_stream_ms, dt / args.steps * 1e3),
                     "note": ("scene is cache-resident (%.1f MB of nodes+triangles): the algorithmic traversal bytes are served by LDS/L1/L2, HBM only "
-                             "carries the path-pool stream, and what binds is VALU issue under divergence + memory latency -- `frac` (vs HBM peak) "
-                             "is kept for continuity, `l2_relative` and `valu_lane_utilisation` are the meaningful gauges" if resident else
-                             "scene (%.1f MB of nodes+triangles) exceeds L2 / Infinity Cache: traversal fetches reach HBM, `frac` is a real HBM fraction")
+                             "carries the path-pool stream, and what binds is VALU issue under divergence + memory latency (valu_issue_frac, "
+                             "valu_lane_utilisation) -- `frac` (vs HBM peak) is the contract's algorithmic figure, `hbm_measured` the real traffic" if resident else
+                             "scene (%.1f MB of nodes+triangles) exceeds L2 / Infinity Cache: traversal fetches reach HBM")
                             % (scene_bytes / 1e6)}
         rpp_ref = (c.rays_primary + c.rays_continuation + c.self_shadow_tests) / max(1, c.paths)
         out = {
-            "metric": "Mray/s (primary+secondary), cornell-box 1024spp", "value": round(total_rays / dt / 1e6, 2), "unit": "Mray/s",
+            "metric": "Mray/s (primary+secondary), %s %dspp" % (cfg["scene"], cfg["spp"]), "value": round(total_rays / dt / 1e6, 2), "unit": "Mray/s",
             "n_gpus": n_ranks, "rccl_ranks": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if (args.shard == "tiles" and n_ranks > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"name": args.config,
                        "workload": "%s, %d spp/step/GPU%s, MIS integrator, reference-faithful shadow rays" % (
                            cfg["label"], spp, "" if spp == cfg["spp"] else " (of the config's %d)" % cfg["spp"]),
-                       "n_tris": int(info.n_tris), "scene_device_bytes": int(info.device_bytes),
+                       "n_tris": int(info.n_tris), "wide_bvh": "%d-wide, %d nodes, depth %d" % (info.wide_width, info.wide_nodes, info.wide_depth), "scene_device_bytes": int(info.device_bytes),
                        "parallelism": "%s shard x%d + RCCL all-reduce of the %dx%dx4 fp32 film" % (
                            "interleaved 8x8 pixel-tile" if args.shard == "tiles" else "sample-range", n_ranks, W, H)},
             "mpath_per_s": round(total_paths / dt / 1e6, 2), "rays_per_path": round(total_rays / max(1.0, total_paths), 3),

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MCPT_ABI_VERSION 2
+#define MCPT_ABI_VERSION 3
 
 typedef enum mcpt_status {
     MCPT_OK = 0,
@@ -118,8 +118,12 @@ typedef struct mcpt_counters {
 typedef struct mcpt_scene_info {
     uint32_t n_tris, n_lights, n_nodes, bvh_depth, max_leaf;
     uint32_t width, height;
-    uint64_t device_bytes;      /* HBM held by the scene (nodes + triangle streams + textures + accumulator) */
+    uint64_t device_bytes;      /* HBM held by the scene (nodes + triangle streams + textures + accumulator + path pools allocated so far) */
     double   bvh_build_ms, upload_ms;
+    /* ABI 3: the wide tree the wavefront trace kernel walks (8 children per node unless a developer knob asked for the 4-wide one) */
+    uint32_t wide_width, wide_nodes, wide_depth, reserved0;
+    uint64_t traversal_bytes;   /* wide nodes + triangle intersection records: what a ray's traversal can touch */
+    double   centre[3];         /* device coordinates are relative to this point (the fp64 centre of the scene's bounding box) */
 } mcpt_scene_info;
 
 typedef struct mcpt_ctx mcpt_ctx;

@@ -146,6 +146,13 @@ struct Scratch {
 
 }  // namespace
 
+static void fill_wide_info(mcpt_scene_info& in, const HostScene& hs) {
+    in.wide_width = hs.bvh_width; in.wide_nodes = uint32_t(hs.bvh_width == 8 ? hs.nodes8.size() / 5 : hs.nodes4.size() / 4);
+    in.wide_depth = hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth;
+    in.traversal_bytes = (hs.nodes4.size() + hs.nodes8.size() + hs.tri_isect.size()) * sizeof(f4h);
+    for (int a = 0; a < 3; a++) in.centre[a] = hs.centre[a];
+}
+
 extern "C" {
 
 uint32_t mcpt_abi_version(void) { return MCPT_ABI_VERSION; }
@@ -164,6 +171,7 @@ mcpt_status mcpt_check_scene(const mcpt_scene_desc* scene, mcpt_scene_info* out_
         out_info->n_tris = uint32_t(hs.tri_face.size()); out_info->n_lights = uint32_t(hs.lights.size()); out_info->n_nodes = uint32_t(hs.nodes.size() / 4);
         out_info->bvh_depth = hs.bvh_depth; out_info->max_leaf = hs.max_leaf; out_info->width = uint32_t(scene->camera.width); out_info->height = uint32_t(scene->camera.height);
         out_info->bvh_build_ms = hs.bvh_build_ms;
+        fill_wide_info(*out_info, hs);
     }
     return MCPT_OK;
 }
@@ -301,6 +309,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes + c->mats.bytes +
                       c->lights.bytes + c->light_pos64.bytes + c->texels.bytes + accum_bytes;
     in.bvh_build_ms = hs.bvh_build_ms;
+    fill_wide_info(in, hs);
     in.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out_ctx = c;
     return MCPT_OK;
