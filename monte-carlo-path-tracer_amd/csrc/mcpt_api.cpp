@@ -220,6 +220,9 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         if ((st = check_device()) != MCPT_OK) return st;
     }
 
+    // the 8-wide trace kernel addresses node and triangle records with 32-bit byte offsets
+    if (hs.bvh_width == 8 && (hs.nodes8.size() * sizeof(f4h) >= (1ull << 32) || hs.tri_isect.size() * sizeof(f4h) >= (1ull << 32)))
+        return fail(MCPT_ERR_UNSUPPORTED, "scene too large for the 8-wide traversal kernel (more than 89 M triangles)");
     mcpt_ctx* c = new mcpt_ctx();
     c->device = o.device; c->opts = o; c->width = scene->camera.width; c->height = scene->camera.height;
     auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };

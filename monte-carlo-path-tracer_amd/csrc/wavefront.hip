@@ -948,6 +948,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     uint32_t slot = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     float idx = 0, idy = 0, idz = 0, tmax = 0;
+    float nox = 0, noy = 0, noz = 0;                                   // -o * (1 / d): the plane offsets of a node then cost one fma each (the register file has room up to 80)
     // cur = the group on top of the lane's stack, held in registers: .y & 0xff != 0 -> inner group G; .y != 0 otherwise -> a leaf group
     // waiting for the parking place; .y == 0 -> bottom of the stack (the ray is finished once T is empty too).  T = the parked leaf group.
     uint32_t cur_x = 0, cur_y = 0, t_x = 0, t_y = 0, oct = 0;
@@ -978,12 +979,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         const uint32_t node = cur_x + (uint32_t)__popc((cur_y >> 8) & ((1u << s) - 1u));
         cur_y &= cur_y - 1u;
         if (node < MCPT_TOP_NODES8) { R0 = top[node]; R1 = top[MCPT_TOP_NODES8 + node]; R2 = top[2 * MCPT_TOP_NODES8 + node]; R3 = top[3 * MCPT_TOP_NODES8 + node]; R4 = top[4 * MCPT_TOP_NODES8 + node]; }
-        else { glb_cf4* n = gnodes + 5 * (size_t)node; R0 = n[0]; R1 = n[1]; R2 = n[2]; R3 = n[3]; R4 = n[4]; }
+        else { glb_cf4* n = (glb_cf4*)((const __attribute__((address_space(1))) char*)gnodes + node * 80u); R0 = n[0]; R1 = n[1]; R2 = n[2]; R3 = n[3]; R4 = n[4]; }   // (32-bit byte offset from a uniform base: saddr + voffset addressing)
     };
     auto inner_consume = [&]() __attribute__((always_inline)) {
         const uint32_t sxy = __float_as_uint(R0.w), masks = __float_as_uint(R1.w);
         const float ax = __uint_as_float(sxy & 0xffff0000u) * idx, ay = __uint_as_float(sxy << 16) * idy, az = __uint_as_float(__float_as_uint(R1.z) & 0xffff0000u) * idz;
-        const float bx = (R0.x - o.x) * idx, by = (R0.y - o.y) * idy, bz = (R0.z - o.z) * idz;
+        const float bx = fmaf(R0.x, idx, nox), by = fmaf(R0.y, idy, noy), bz = fmaf(R0.z, idz, noz);
         const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
         // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise
         const uint32_t xl0 = __float_as_uint(R2.x), xl1 = __float_as_uint(R2.y), xh0 = __float_as_uint(R2.z), xh1 = __float_as_uint(R2.w);
@@ -1089,9 +1090,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     }
                     if (valid) {
                         const float tiny = 1e-30f;
-                        idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
-                        idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
-                        idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+                        // v_rcp_f32 (1 ulp) instead of the IEEE divide sequence (~10 VALU issues each, executed for the ~19 lanes a refill feeds):
+                        // the child boxes carry ~16 ulp of padding for exactly this kind of rounding in the slab arithmetic
+                        idx = __builtin_amdgcn_rcpf(fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+                        idy = __builtin_amdgcn_rcpf(fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+                        idz = __builtin_amdgcn_rcpf(fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+                        nox = -o.x * idx; noy = -o.y * idy; noz = -o.z * idz;
                         // the visiting order only matters to closest-hit rays (Render.cpp:125 asks whether the light is visible at all):
                         // any-hit rays keep octant 0, i.e. slot order -- and a wave that carries no closest-hit ray skips the permutation
                         oct = any ? 0u : ((idx < 0.0f ? 1u : 0u) | (idy < 0.0f ? 2u : 0u) | (idz < 0.0f ? 4u : 0u));
@@ -1126,7 +1130,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 for (uint32_t i = 0; i < cnt && !done; i += 2) {
                     const int ta = (int)(first + i), tb = ta + 1;
                     const bool use_a = !(any && ta == htri), use_b = i + 1 < cnt && !(any && tb == htri);   // any-hit rays keep their `skip` triangle in htri
-                    const float4* T = sc.tri_isect + 3 * (size_t)ta;
+                    const float4* T = (const float4*)((const char*)sc.tri_isect + (uint32_t)ta * 48u);   // (n_tris < 2^28 x 48 B would overflow 32 bits: checked at launch)
                     float4 v0a = make_float4(0, 0, 0, 0), e1a = v0a, e2a = v0a, v0b = v0a, e1b = v0a, e2b = v0a;
                     if (use_a) { v0a = T[0]; e1a = T[1]; e2a = T[2]; }
                     if (use_b) { v0b = T[3]; e1b = T[4]; e2b = T[5]; }
