@@ -264,16 +264,12 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             uint32_t n_lanes = env_u32("MCPT_WF_LANES", 2);
             if (n_lanes < 1) n_lanes = 1;
             if (o.flags & MCPT_FLAG_DETERMINISTIC) n_lanes = 1;          // one owner per pixel, plain stores
-            // Persistent trace grid.  One sub-pipeline: fill every CU (2 blocks = 32 waves).  Two: the trace of one runs beside the
-            // shade (or trace) of the other.  While the traversal data (4-wide nodes + triangle records) is cache-resident the pair is
-            // fastest with ~14 trace waves per CU -- grid = 7/8 of the CUs (r02, 72-register trace beside the 104-register sorted shade:
-            // 485 / 478 / 466 / 474 ms at 160 / 192 / 224 / 256 blocks on the bench workload; r01's 132-register shade wanted 3/4) --
-            // the rest of each CU's registers go to shade waves.  Once it spills out of L2
-            // the trace kernel is the longer pole and wants every slot: 345 vs 366 ms at 48 MB, 838 vs 904 ms at 350 MB.
+            // Persistent trace grid: one 1024-thread block (16 waves, 78 VGPRs) per CU -- what the register file admits beside two shade
+            // waves per SIMD (4 x 80 + 2 x 96 = 512).  Rounds 1-2 launched 3/4 and 7/8 of the CUs while the traversal data was
+            // cache-resident (their 72-register kernel left room for a second block on some CUs); r03, 8-wide kernel, S-cornell 512 spp:
+            // 214.6 / 217.5 / 211.6 / 213.4 / 208.5 ms at 192 / 208 / 224 / 240 / 256 blocks.  MCPT_WF_GRID overrides.
             const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0, hs.bvh_width));
-            const size_t traversal_bytes = (hs.nodes4.size() + hs.nodes8.size()) * sizeof(f4h) + hs.tri_isect.size() * sizeof(f4h);
-            const bool cache_resident = traversal_bytes <= (size_t(16) << 20);
-            c->trace_grid = (n_lanes > 1 && cache_resident) ? std::max(1u, uint32_t(c->n_cus) * 7u / 8u) : uint32_t(c->n_cus) * per_cu;
+            c->trace_grid = uint32_t(c->n_cus) * per_cu;
             c->trace_grid = std::min(env_u32("MCPT_WF_GRID", c->trace_grid), uint32_t(c->n_cus) * per_cu);
             // speculative traversal: S-cornell 469 -> 450 ms; on the 4 M-triangle configuration, where the extra node visits are HBM
             // traffic, it is neutral within the noise (same box: 367 ms with, 371 ms without) -- on everywhere; MCPT_WF_PEND=0 turns it off

@@ -57,6 +57,9 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {            // num
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 __device__ __forceinline__ uint32_t wave_first(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// A wave-uniform word written by an EARLIER launch, through the scalar cache (the compiler only does this by itself where it can prove that no
+// store of the kernel aliases it; a vector load + readfirstlane costs a vmcnt(0) round trip instead).
+__device__ __forceinline__ uint32_t s_load_u32(const uint32_t* p) { uint32_t v; asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory"); return v; }
 
 // ====================================================================================================== shade
 // Branch-sorted shading.  The reference assembles a different lobe set per material (BSDF.cpp:95-107) and a path may end at
@@ -929,7 +932,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         const bool none = c >= n_chunks, ext = cc < n_ext_chunks, shadow = !none && !ext;
         const uint32_t b = shadow ? cc - n_ext_chunks : 0u;
         uint32_t cnt = ext ? (uint32_t)WF_SHADE_BLOCK : 0u;
-        if (shadow) cnt = wave_first(ld_s(&pool.shadow_count[b]));
+        if (shadow) cnt = s_load_u32(&pool.shadow_count[b]);            // (uniform address, written by the shade launch before this one)
         const uint32_t lo = min(part * span, cnt), hi = min(lo + span, cnt), base = ext ? cc * WF_SHADE_BLOCK : 0u;
         exhausted = exhausted || none;
         chunk_shadow = shadow;
