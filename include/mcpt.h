@@ -194,6 +194,10 @@ mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, co
 mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, const double* t2, int any_hit,
                               float* out_t, int32_t* out_tri, float* out_u, float* out_v);
 /* Render::cast_Ray (Render.cpp:71-80) for n (x,y) pixels with the xi the caller supplies (2 per ray). */
+/* Triangle::hit's shading record (Triangle.cpp:68-76: interplote_Normal, normalize, interplote_uv, front = dot(n, d) < 0) for hits the
+ * caller got from mcpt_probe_trace4: `face` = Model::face index, (u, v) = the hit's barycentrics, dir = the ray's direction.
+ * out6 per hit = normal xyz | uv | front (1 / 0). */
+mcpt_status mcpt_probe_hit_shade(mcpt_ctx* ctx, uint32_t n, const int32_t* face, const float* u, const float* v, const double* dir, float* out6);
 mcpt_status mcpt_probe_cast_ray(mcpt_ctx* ctx, uint32_t n, const int32_t* xy, const float* xi, float* out_origin_dir6);
 /* BSDF (BSDF.cpp:87-202) on synthetic hits: per item normal[3], wi[3], kd[3], ks[3], ns, wo[3] (world) and 3 xi
  * {lobe, xi1, xi2}.  out per item: Fx(wo)[3], Pdf(wo), sample.wo[3], sample.f[3], sample.pdf, isMirror = 12 floats */

@@ -174,6 +174,7 @@ def load_library() -> C.CDLL:
         "mcpt_probe_trace4": [vp, C.c_uint32, vp, vp, vp, C.c_int, vp, vp, vp, vp],
         "mcpt_probe_trace": [vp, C.c_uint32, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp],
         "mcpt_probe_cast_ray": [vp, C.c_uint32, vp, vp, vp],
+        "mcpt_probe_hit_shade": [vp, C.c_uint32, vp, vp, vp, vp, vp],
         "mcpt_probe_bsdf": [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp],
         "mcpt_probe_sample_light": [vp, C.c_uint32, vp, vp, vp],
         "mcpt_probe_paths": [vp, C.c_uint32, vp, vp, C.c_uint64, vp],
@@ -196,7 +197,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_create", "mcpt_destroy", "mcpt_check_scene", "mcpt_get_scene_info", "mcpt_last_error", "mcpt_abi_version",
     "mcpt_render", "mcpt_render_tiles", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap",
     "mcpt_get_counters", "mcpt_reset_counters", "mcpt_bind_accum", "mcpt_accum_device_ptr", "mcpt_set_stream",
-    "mcpt_set_null_stream", "mcpt_probe_trace", "mcpt_probe_trace4", "mcpt_probe_cast_ray", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
+    "mcpt_set_null_stream", "mcpt_probe_trace", "mcpt_probe_trace4", "mcpt_probe_cast_ray", "mcpt_probe_hit_shade", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
     "mcpt_probe_paths", "mcpt_probe_rng", "mcpt_probe_texture",
 ]
 
@@ -328,6 +329,13 @@ class Renderer:
         self._check(self.lib.mcpt_probe_trace4(self.ctx, n, _ptr(o), _ptr(d), _ptr(t2), 1 if any_hit else 0,
                                                _ptr(ot), _ptr(tri), _ptr(u), _ptr(v)))
         return ot, tri, u, v
+
+    def probe_hit_shade(self, face, u, v, direction):
+        face = np.ascontiguousarray(face, np.int32); u = np.ascontiguousarray(u, np.float32); v = np.ascontiguousarray(v, np.float32)
+        d = np.ascontiguousarray(direction, np.float64).reshape(-1, 3); n = face.shape[0]
+        out = np.zeros((n, 6), np.float32)
+        self._check(self.lib.mcpt_probe_hit_shade(self.ctx, n, _ptr(face), _ptr(u), _ptr(v), _ptr(d), _ptr(out)))
+        return out
 
     def probe_cast_ray(self, xy, xi):
         xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2); xi = np.ascontiguousarray(xi, np.float32).reshape(-1, 2)

@@ -318,6 +318,14 @@ __global__ void probe_cast_ray_kernel(DevScene sc, uint32_t n, const int* xy, co
     out6[6 * i + 0] = o.x; out6[6 * i + 1] = o.y; out6[6 * i + 2] = o.z; out6[6 * i + 3] = d.x; out6[6 * i + 4] = d.y; out6[6 * i + 5] = d.z;
 }
 
+// Triangle::hit's shading record (Triangle.cpp:68-76) for a given hit: interpolated + normalised vertex normal, uv, front flag
+__global__ void probe_hit_shade_kernel(DevScene sc, uint32_t n, const int* tri, const float* u, const float* v, const double* dir, float* out6) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const HitShade h = load_hit_shade(sc, tri[i], u[i], v[i], mk3((float)dir[3 * i], (float)dir[3 * i + 1], (float)dir[3 * i + 2]));
+    out6[6 * i + 0] = h.n.x; out6[6 * i + 1] = h.n.y; out6[6 * i + 2] = h.n.z; out6[6 * i + 3] = h.tu; out6[6 * i + 4] = h.tv; out6[6 * i + 5] = h.front ? 1.f : 0.f;
+}
+
 __global__ void probe_bsdf_kernel(uint32_t n, const float* normal, const float* wi, const float* kd, const float* ks, const float* ns,
                                   const float* wo, const float* xi, float* out12) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,6 +399,10 @@ hipError_t launch_probe_trace(const DevScene& sc, uint32_t n, const double* o, c
 }
 hipError_t launch_probe_cast_ray(const DevScene& sc, uint32_t n, const int* xy, const float* xi, float* out6, hipStream_t stream) {
     hipLaunchKernelGGL(probe_cast_ray_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, xy, xi, out6);
+    return hipGetLastError();
+}
+hipError_t launch_probe_hit_shade(const DevScene& sc, uint32_t n, const int* tri, const float* u, const float* v, const double* dir, float* out6, hipStream_t stream) {
+    hipLaunchKernelGGL(probe_hit_shade_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, tri, u, v, dir, out6);
     return hipGetLastError();
 }
 hipError_t launch_probe_bsdf(uint32_t n, const float* normal, const float* wi, const float* kd, const float* ks, const float* ns, const float* wo,

@@ -777,6 +777,28 @@ mcpt_status mcpt_probe_cast_ray(mcpt_ctx* ctx, uint32_t n, const int32_t* xy, co
     return MCPT_OK;
 }
 
+mcpt_status mcpt_probe_hit_shade(mcpt_ctx* ctx, uint32_t n, const int32_t* face, const float* u, const float* v, const double* dir, float* out6) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!face || !u || !v || !dir || !out6) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MCPT_OK;
+    if (ctx->h_tri_face.empty()) {
+        ctx->h_tri_face.resize(size_t(ctx->dev.n_tris));
+        HIP_TRY(hipMemcpy(ctx->h_tri_face.data(), ctx->dev.tri_face, ctx->h_tri_face.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    std::vector<int32_t> leaf_of_face(ctx->h_tri_face.size(), -1), tri(n);
+    for (size_t i = 0; i < ctx->h_tri_face.size(); i++) leaf_of_face[size_t(ctx->h_tri_face[i])] = int32_t(i);
+    for (uint32_t i = 0; i < n; i++) {
+        if (face[i] < 0 || size_t(face[i]) >= leaf_of_face.size()) return fail(MCPT_ERR_INVALID_ARG, "mcpt_probe_hit_shade: face index out of range");
+        tri[i] = leaf_of_face[size_t(face[i])];
+    }
+    Scratch s; int* d_tri; float *d_u, *d_v, *d_out; double* d_d;
+    HIP_TRY(s.in(tri.data(), n, &d_tri)); HIP_TRY(s.in(u, n, &d_u)); HIP_TRY(s.in(v, n, &d_v)); HIP_TRY(s.in(dir, 3 * size_t(n), &d_d)); HIP_TRY(s.out(6 * size_t(n), &d_out));
+    HIP_TRY(launch_probe_hit_shade(ctx->dev, n, d_tri, d_u, d_v, d_d, d_out, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out6, d_out, 6 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
 mcpt_status mcpt_probe_bsdf(mcpt_ctx* ctx, uint32_t n, const float* normal, const float* wi, const float* kd, const float* ks, const float* ns,
                             const float* wo, const float* xi, float* out12) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;

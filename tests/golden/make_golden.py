@@ -17,6 +17,9 @@ Files:
                        exponents 10..5000) and S-bath small (image textures, mirror Ns = 10000, glossy chrome): injected-xi full
                        paths, BVH::hit / has_hit ray records, light samples, and default-mode mean / variance images
                        (`python tests/golden/make_golden.py scenes2` writes only this file)
+  ref_fullsize_<c>.npz (round 3) 8x8-block mean / variance-of-the-mean maps of the real reference at the bench configurations' own sizes
+                       (c2: S-cornell 800x800 depth 8; c3: S-veach 1280x720; c4s: S-bath 93 k triangles 1920x1080), 128 spp each
+                       (`... make_golden.py fullsize c2` etc.: one configuration per process, tens of CPU-minutes each)
   ref_loader.npz       (round 2) the reference's own Model(filename) parse of tests/golden/loader_quirks/quirk.obj (this project's
                        quirk-exercising input) and of a scenes.py-written S-bath small (`... make_golden.py loader`)
 """
@@ -183,6 +186,42 @@ def image_stats(scene, lib_depth, max_bounces, frames, batches):
     return means.mean(0).astype(np.float32), (means.var(0, ddof=1) / batches).astype(np.float32)
 
 
+
+# ---- full-size block statistics (round 3): the BENCH configurations themselves, pinned to the real reference ------------------------
+FULLSIZE = {   # tag: (generator, kwargs, (w, h), depth limit (0 = the reference's unbounded loop), batches, frames per batch)
+    "c2": ("cornell-box", {}, (800, 800), 8, 8, 16),
+    "c3": ("veach-mis", {}, (1280, 720), 0, 8, 16),
+    "c4s": ("bathroom2", {"detail": 64}, (1920, 1080), 0, 8, 16),
+}
+
+
+def block_means(img, b=8):
+    h, w = img.shape[0] // b * b, img.shape[1] // b * b
+    return img[:h, :w].reshape(h // b, b, w // b, b, img.shape[2]).mean((1, 3))
+
+
+def fullsize(tag):
+    """8 x 8-pixel block means of the real reference at a bench configuration's own resolution: mean and variance-of-the-mean over
+    `batches` independent batches (single pixels fed by a hundred heavy-tailed samples are far from normal; block means are not)."""
+    name, kw, (w, h), depth, batches, frames = FULLSIZE[tag]
+    scene = pkg.scenes.SCENES[name](w, h, **kw)
+    ref = orc.Reference(depth_variant=depth > 0)
+    ref.load(scene.write(tempfile.mkdtemp(prefix="mcpt_golden_")))
+    ref.stream_mode()
+    if depth: ref.set_max_bounces(depth)
+    import time
+    t0 = time.time(); bm = []
+    for b in range(batches):
+        ref.clear(); ref.render(frames)
+        a = ref.accum(); bm.append(block_means(a[..., :3] / a[..., 3:]))
+        print("[fullsize %s] batch %d / %d  (%.0f s)" % (tag, b + 1, batches, time.time() - t0), flush=True)
+    bm = np.stack(bm)
+    np.savez_compressed(os.path.join(HERE, "ref_fullsize_%s.npz" % tag), mean=bm.mean(0).astype(np.float32), var=(bm.var(0, ddof=1) / batches).astype(np.float32),
+                        spp=np.int32(batches * frames), batches=np.int32(batches), block=np.int32(8), depth=np.int32(depth),
+                        image_mean=bm.mean((0, 1, 2)).astype(np.float64))
+    print("[fullsize %s] image mean %s" % (tag, bm.mean((0, 1, 2))))
+
+
 SCENES2 = {   # tag: (generator, kwargs, (w, h), box the probe rays / shading points are drawn from)
     "vm_": ("veach-mis", {"light_lon": 12, "light_lat": 6, "plate_cells": 4}, (64, 36), ((-6.0, 0.0, -5.0), (6.0, 6.0, 8.0))),
     "bt_": ("bathroom2", {"detail": 12, "tex_size": 32}, (64, 36), ((0.1, 0.1, 0.1), (3.9, 2.5, 4.9))),
@@ -263,6 +302,8 @@ def main():
         scenes2(); return
     if len(sys.argv) > 1 and sys.argv[1] == "loader":
         loader(); return
+    if len(sys.argv) > 2 and sys.argv[1] == "fullsize":                    # one configuration per process (tens of CPU-minutes each): c2 | c3 | c4s
+        fullsize(sys.argv[2]); return
     scene = pkg.scenes.cornell_box_small(64, 64)
     tmp = tempfile.mkdtemp(prefix="mcpt_golden_")
     ref = orc.Reference()

@@ -192,7 +192,7 @@ def test_gpu_matches_reference_statistics(pkg, images, name, max_depth, scene_fn
     z = np.abs(mean - rm) / np.sqrt(var + rv + 1e-12)
     frac = float((z > 4).mean())
     print(name, "gpu", mean.mean((0, 1)), "reference", rm.mean((0, 1)), "pixels > 4 sigma %.3f%%" % (100 * frac))
-    assert frac <= 0.006
+    assert frac <= 0.003                                                  # SURVEY section 8(d) / BASELINE.md: <= 0.3 % of pixels beyond 4 sigma (measured <= 0.16 %)
 
 
 SCENES2 = {"vm_": ("veach-mis", {"light_lon": 12, "light_lat": 6, "plate_cells": 4}, (64, 36)),
@@ -224,7 +224,7 @@ def test_gpu_matches_reference_statistics_more_scenes(pkg, g2, tag):
     frac = float((z > 4).mean())
     print(tag, "gpu", mean.mean((0, 1)), "reference", rm.mean((0, 1)), "se", se, "pixels > 4 sigma %.3f%%" % (100 * frac))
     assert np.all(dm <= 4 * se) and np.all(dm <= 0.03 * rm.mean((0, 1)))
-    assert frac <= 0.006
+    assert frac <= 0.003                                                  # the contract's 0.3 % (measured <= 0.16 %)
 
 
 @pytest.mark.parametrize("tag", sorted(SCENES2))
@@ -327,6 +327,25 @@ def test_probe_trace4_hot_kernel_vs_reference(pkg, paths, tree, grid):
     same = tri4 == tri2
     assert same.mean() >= 0.9995
     _same_numbers(t4[same], t2_[same], u4[same], u2[same], v4[same], v2[same])
+
+
+def test_probe_hit_shade_vs_reference(pkg, paths):
+    """Triangle::hit's shading record (Triangle.cpp:35-46, 68-76: interpolated + normalised vertex normal, interpolated uv, front flag) on
+    the reference's own 4 000 rays: the production trace kernel finds the hit (mcpt_probe_trace4), load_hit_shade -- the function the shade
+    kernel calls -- turns (triangle, u, v) into the record, and the reference's fp64 record (cs_ray_rec[:, 4:10]) is the yardstick:
+    normal and uv to 2e-6 absolute (fp32 barycentrics against fp64 ones), front flag equal wherever |n.d| is not within rounding of 0."""
+    p = paths
+    r = pkg.Renderer(pkg.scenes.cornell_box_small(64, 64))
+    t, tri, u, v = r.probe_trace4(p["cs_ray_o"], p["cs_ray_d"])
+    ref_tri = p["cs_ray_rec"][:, 11].astype(np.int32); ok = (p["cs_ray_hit"] == 1) & (tri == ref_tri)
+    assert ok.sum() >= 0.99 * (p["cs_ray_hit"] == 1).sum()
+    rec = r.probe_hit_shade(tri[ok], u[ok], v[ok], p["cs_ray_d"][ok]); r.close()
+    ref = p["cs_ray_rec"][ok]
+    assert np.allclose(rec[:, 0:3], ref[:, 4:7], atol=2e-6), np.abs(rec[:, 0:3] - ref[:, 4:7]).max()
+    assert np.allclose(rec[:, 3:5], ref[:, 7:9], atol=2e-6), np.abs(rec[:, 3:5] - ref[:, 7:9]).max()
+    nd = np.abs((ref[:, 4:7] * p["cs_ray_d"][ok]).sum(-1))
+    clear = nd > 1e-5
+    assert np.array_equal(rec[clear, 5], ref[clear, 9].astype(np.float32)) and clear.mean() > 0.99
 
 
 def _needle_forest(pkg, n_needles=6000, seed=5):
@@ -1090,3 +1109,48 @@ def test_exact_ties_have_a_defined_winner(pkg):
     r.clear(); r.render(16, seed=5); c = r.read_accum(); r.close()
     assert np.all(a[..., 3] == 16) and np.isfinite(a).all()
     assert np.allclose(a, b, rtol=1e-4, atol=1e-4) and np.allclose(a, c, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ the bench configurations themselves
+@pytest.mark.parametrize("tag", ["c2", "c3", "c4s"])
+def test_full_size_block_statistics_vs_reference(pkg, tag):
+    """The BENCH configurations at their own resolution against the REAL reference (tests/golden/ref_fullsize_<tag>.npz, written by
+    make_golden.py from oracle/_ref: 8 batches x 16 spp = 128 spp, as 8x8-pixel block means with their batch-to-batch variance):
+    c2 = S-cornell 800x800 depth 8, c3 = S-veach 1280x720 unbounded, c4s = S-bath (93 k triangles) 1920x1080 unbounded.  The GPU renders
+    32 batches x 32 spp, so the statistic z = |difference of block means| / sqrt(var_gpu + var_ref) is carried by the reference's variance
+    estimate from 8 batches: Student t with 7 degrees of freedom -- 0.52 % of blocks beyond 4 and a median |z| of 0.71 are what
+    IDENTICAL renderers give.  Asserted: image mean within 1 %, at most 1 % of blocks beyond 4, median |z| in [0.6, 0.85]."""
+    path = os.path.join(G, "ref_fullsize_%s.npz" % tag)
+    if not os.path.exists(path): pytest.skip(path + " not generated")
+    g = _npz("ref_fullsize_%s.npz" % tag)
+    name, kw, (w, h) = {"c2": ("cornell-box", {}, (800, 800)), "c3": ("veach-mis", {}, (1280, 720)), "c4s": ("bathroom2", {"detail": 64}, (1920, 1080))}[tag]
+    r = pkg.Renderer(pkg.scenes.SCENES[name](w, h, **kw), max_depth=int(g["depth"]))
+    B, S, b = 32, 32, int(g["block"])
+    bm = []
+    for k in range(B):
+        r.clear(); r.render(S, seed=777, first_sample=k * S); a = r.read_accum(); m = a[..., :3] / a[..., 3:]
+        bm.append(m[:h // b * b, :w // b * b].reshape(h // b, b, w // b, b, 3).mean((1, 3)))
+    r.close()
+    bm = np.stack(bm); gm, gv = bm.mean(0), bm.var(0, ddof=1) / B
+    rm, rv = g["mean"], g["var"]
+    z = np.abs(gm - rm) / np.sqrt(gv + rv + 1e-14)
+    f4, f3, med = float((z > 4).mean()), float((z > 3).mean()), float(np.median(z))
+    rel = (gm.mean((0, 1)) - rm.mean((0, 1))) / rm.mean((0, 1))
+    print("%s: image mean gpu %s reference %s (rel %s); blocks beyond 4 sigma %.3f %%, beyond 3 sigma %.3f %% (t7: 0.52 / 1.99), median |z| %.3f (t7: 0.711)" % (
+        tag, gm.mean((0, 1)), rm.mean((0, 1)), rel, 100 * f4, 100 * f3, med))
+    assert np.all(np.abs(rel) <= 0.01)
+    assert f4 <= 0.01 and 0.6 <= med <= 0.85
+
+
+def test_c1_own_size_vs_oracle(pkg, orc):
+    """BASELINE.json configs[0] at its own size -- cornell-box 256x256, 16 spp, depth 4 -- same seed against the fp64 oracle (the
+    config is the reference's CPU plumbing case; here it pins the GPU path at that size): >= 99.9 % of pixels within 1e-4 * max(1, mean)."""
+    scene = pkg.scenes.cornell_box(256, 256)
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    r = pkg.Renderer(scene, max_depth=4, flags=flags); r.render(16, seed=11); g = r.read_accum(); c = r.counters(); r.close()
+    cpu, oc, _ = orc.Oracle(scene, max_depth=4, flags=flags).render(16, seed=11)
+    assert np.all(g[..., 3] == 16)
+    frac = _frac_beyond(g[..., :3] / 16, cpu[..., :3] / 16)
+    print("C1 256x256x16 spp depth 4: pixels beyond tolerance %.3f %%" % (100 * frac))
+    assert frac <= 0.001
+    assert abs(c.rays - (oc["rays_primary"] + oc["rays_continuation"] + oc["rays_shadow"])) <= 0.01 * c.rays
