@@ -135,6 +135,9 @@ typedef struct mcpt_ctx mcpt_ctx;
  * uploads everything to HBM.  Allocates a zeroed width*height accumulator. */
 mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcpt_ctx** out_ctx);
 mcpt_status mcpt_destroy(mcpt_ctx* ctx);
+/* A second context for the same scene on device `device` (may equal the source's): the scene streams are copied device to device, nothing is
+ * flattened or built again.  The clone has its own film, counters, stream and options (those of `src`, device replaced). */
+mcpt_status mcpt_clone_to_device(mcpt_ctx* src, int32_t device, mcpt_ctx** out_ctx);
 /* Host-only half of mcpt_create: validates `scene` (same error codes) and runs the same flatten + BVH build, without
  * touching a device.  Fills n_tris / n_lights / n_nodes / bvh_depth / max_leaf / width / height / bvh_build_ms. */
 mcpt_status mcpt_check_scene(const mcpt_scene_desc* scene, mcpt_scene_info* out_info);
@@ -165,6 +168,8 @@ mcpt_status mcpt_clear_accum(mcpt_ctx* ctx);
  * flip_y != 0 additionally applies Scene::save_image's vertical flip (Scene.cpp:40-46). */
 mcpt_status mcpt_tonemap(mcpt_ctx* ctx, uint8_t* rgb_host, int flip_y);
 
+/* mcpt_tonemap of any film of this context's size resident on its device (e.g. several devices' films summed into a scratch buffer). */
+mcpt_status mcpt_tonemap_buffer(mcpt_ctx* ctx, const void* device_rgba, uint8_t* rgb_host, int flip_y);
 mcpt_status mcpt_get_counters(mcpt_ctx* ctx, mcpt_counters* out);  /* synchronises */
 mcpt_status mcpt_reset_counters(mcpt_ctx* ctx);
 

@@ -168,6 +168,8 @@ def load_library() -> C.CDLL:
         "mcpt_get_counters": [vp, P(Counters)],
         "mcpt_reset_counters": [vp],
         "mcpt_bind_accum": [vp, vp],
+        "mcpt_clone_to_device": [vp, C.c_int32, P(vp)],
+        "mcpt_tonemap_buffer": [vp, vp, vp, C.c_int],
         "mcpt_accum_device_ptr": [vp, P(vp)],
         "mcpt_set_stream": [vp, vp],
         "mcpt_set_null_stream": [vp],
@@ -194,7 +196,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "mcpt_create", "mcpt_destroy", "mcpt_check_scene", "mcpt_get_scene_info", "mcpt_last_error", "mcpt_abi_version",
+    "mcpt_create", "mcpt_destroy", "mcpt_clone_to_device", "mcpt_tonemap_buffer", "mcpt_check_scene", "mcpt_get_scene_info", "mcpt_last_error", "mcpt_abi_version",
     "mcpt_render", "mcpt_render_tiles", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap",
     "mcpt_get_counters", "mcpt_reset_counters", "mcpt_bind_accum", "mcpt_accum_device_ptr", "mcpt_set_stream",
     "mcpt_set_null_stream", "mcpt_probe_trace", "mcpt_probe_trace4", "mcpt_probe_cast_ray", "mcpt_probe_hit_shade", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
@@ -232,6 +234,14 @@ class Renderer:
         o.integrator = integrator; o.flags = flags; o.samples_per_item = samples_per_item
         self.ctx = C.c_void_p()
         self._check(self.lib.mcpt_create(C.byref(self.holder.desc), C.byref(o), C.byref(self.ctx)))
+
+    def clone(self, device=0) -> "Renderer":
+        """A second Renderer for the same scene (mcpt_clone_to_device): no flatten, no BVH build."""
+        other = Renderer.__new__(Renderer)
+        other.lib = self.lib; other.holder = self.holder; other.width, other.height = self.width, self.height
+        other.ctx = C.c_void_p()
+        self._check(self.lib.mcpt_clone_to_device(self.ctx, int(device), C.byref(other.ctx)))
+        return other
 
     def _check(self, status):
         if status != MCPT_OK:
@@ -275,6 +285,16 @@ class Renderer:
     def tonemap(self, flip_y=False) -> np.ndarray:
         out = np.zeros((self.height, self.width, 3), np.uint8)
         self._check(self.lib.mcpt_tonemap(self.ctx, _ptr(out), 1 if flip_y else 0))
+        return out
+
+    def accum_device_ptr(self) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.mcpt_accum_device_ptr(self.ctx, C.byref(p)))
+        return p.value
+
+    def tonemap_buffer(self, device_ptr: int, flip_y=False) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        self._check(self.lib.mcpt_tonemap_buffer(self.ctx, C.c_void_p(device_ptr), _ptr(out), 1 if flip_y else 0))
         return out
 
     def counters(self) -> Counters:

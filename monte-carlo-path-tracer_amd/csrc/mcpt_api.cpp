@@ -65,6 +65,7 @@ struct mcpt_ctx {
     double last_trace_ms = 0.0, total_trace_ms = 0.0, last_shade_ms = 0.0, total_shade_ms = 0.0;
     uint64_t total_iterations = 0;
     bool binary_ok = true;                // the binary cross-check tree fits its kernels' stack (false: a deep device-built tree)
+    uint32_t wide_width = 8, wide_depth = 0;   // the wide tree the wavefront trace kernel walks
     std::vector<int32_t> h_tri_face;      // leaf order -> face index, fetched on first use by mcpt_probe_trace4
 };
 
@@ -146,6 +147,73 @@ struct Scratch {
 
 }  // namespace
 
+// Everything of a context that is not the scene: streams, events, film, counters, the wavefront sub-pipelines, and the device pointers of
+// c->dev (the scene streams c->nodes ... c->texels are on the device already: uploaded by mcpt_create or copied by mcpt_clone_to_device).
+static mcpt_status finish_ctx(mcpt_ctx* c) {
+    hipError_t e = hipSuccess;
+    auto bail = [&](hipError_t he, const char* what) { return hip_fail(he, what); };
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    c->stream = c->own_stream;
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    const size_t accum_bytes = size_t(c->width) * c->height * sizeof(float4);
+    if ((e = c->accum_own.alloc(accum_bytes)) != hipSuccess) return bail(e, "alloc accumulator");
+    if ((e = hipMemset(c->accum_own.p, 0, accum_bytes)) != hipSuccess) return bail(e, "clear accumulator");
+    if ((e = c->counters.alloc(sizeof(DevCounters) * WF_COUNTER_REPLICAS)) != hipSuccess) return bail(e, "alloc counters");
+    if ((e = hipMemset(c->counters.p, 0, sizeof(DevCounters) * WF_COUNTER_REPLICAS)) != hipSuccess) return bail(e, "clear counters");
+    {   // ---- wavefront pool.  Tunables are developer knobs (environment), not part of the ABI.
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, c->device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+        c->n_cus = prop.multiProcessorCount;
+        const char* pipe = std::getenv("MCPT_PIPELINE");
+        c->use_wavefront = !(pipe && std::string(pipe) == "mega") && c->opts.integrator == MCPT_INTEGRATOR_MIS;
+        c->pool_cap = 1u << std::min(26u, env_u32("MCPT_WF_POOL_LOG2", 23));
+        if (c->pool_cap < 2048) c->pool_cap = 2048;
+        c->items_per_slot = std::max(1u, env_u32("MCPT_WF_ITEMS_PER_SLOT", 1));
+        c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
+        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0); c->tune.pend_cap = 48;      // speculative traversal: refined below once the scene's size is known
+        c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0);
+        if (c->use_wavefront) {
+            uint32_t n_lanes = env_u32("MCPT_WF_LANES", 2);
+            if (n_lanes < 1) n_lanes = 1;
+            if (c->opts.flags & MCPT_FLAG_DETERMINISTIC) n_lanes = 1;          // one owner per pixel, plain stores
+            // Persistent trace grid: one 1024-thread block (16 waves, 78 VGPRs) per CU -- what the register file admits beside two shade
+            // waves per SIMD (4 x 80 + 2 x 96 = 512).  Rounds 1-2 launched 3/4 and 7/8 of the CUs while the traversal data was
+            // cache-resident (their 72-register kernel left room for a second block on some CUs); r03, 8-wide kernel, S-cornell 512 spp:
+            // 214.6 / 217.5 / 211.6 / 213.4 / 208.5 ms at 192 / 208 / 224 / 240 / 256 blocks.  MCPT_WF_GRID overrides.
+            const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((c->opts.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0, c->wide_width));
+            c->trace_grid = uint32_t(c->n_cus) * per_cu;
+            c->trace_grid = std::min(env_u32("MCPT_WF_GRID", c->trace_grid), uint32_t(c->n_cus) * per_cu);
+            // speculative traversal: S-cornell 469 -> 450 ms; on the 4 M-triangle configuration, where the extra node visits are HBM
+            // traffic, it is neutral within the noise (same box: 367 ms with, 371 ms without) -- on everywhere; MCPT_WF_PEND=0 turns it off
+            c->tune.pend_cap = env_u32("MCPT_WF_PEND", 48u);
+            if ((e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+            c->lanes.resize(n_lanes);
+            for (auto& L : c->lanes) {
+                L.pool.P = 0;                                             // allocated by ensure_pool() when the first job arrives
+                if ((e = L.ctl_buf.alloc(sizeof(IterCtl))) != hipSuccess) return bail(e, "alloc IterCtl");
+                if ((e = hipHostMalloc((void**)&L.h_ctl, 8 * sizeof(IterCtl), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+                L.chk_ev.resize(8);
+                for (auto& ev : L.chk_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+                if ((e = hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+                if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+                if ((e = L.ovf_buf.alloc(size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_bytes_per_lane(c->wide_depth, c->wide_width))) != hipSuccess)
+                    return bail(e, "alloc stack overflow area");
+            }
+        }
+    }
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "sync after upload");
+    c->accum = static_cast<float4*>(c->accum_own.p);
+    DevScene& d = c->dev;
+    d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes4 = static_cast<const float4*>(c->nodes4.p); d.nodes8 = static_cast<const float4*>(c->nodes8.p);
+    d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
+    d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p); d.tri_plane64 = static_cast<const double*>(c->tri_plane64.p);
+    d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
+    d.lights = static_cast<const DevLight*>(c->lights.p); d.light_pos64 = static_cast<const double*>(c->light_pos64.p); d.texels = static_cast<const float4*>(c->texels.p);
+    c->info.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes +
+                           c->mats.bytes + c->lights.bytes + c->light_pos64.bytes + c->texels.bytes + accum_bytes;
+    return MCPT_OK;
+}
+
 static void fill_wide_info(mcpt_scene_info& in, const HostScene& hs) {
     in.wide_width = hs.bvh_width; in.wide_nodes = uint32_t(hs.bvh_width == 8 ? hs.nodes8.size() / 5 : hs.nodes4.size() / 4);
     in.wide_depth = hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth;
@@ -225,12 +293,10 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         return fail(MCPT_ERR_UNSUPPORTED, "scene too large for the 8-wide traversal kernel (more than 89 M triangles)");
     mcpt_ctx* c = new mcpt_ctx();
     c->device = o.device; c->opts = o; c->width = scene->camera.width; c->height = scene->camera.height;
+    c->wide_width = hs.bvh_width; c->wide_depth = hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth; c->binary_ok = hs.binary_ok;
     auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };
     if ((e = hipSetDevice(c->device)) != hipSuccess) return bail(e, "hipSetDevice");
     auto t0 = std::chrono::steady_clock::now();
-    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    c->stream = c->own_stream;
-    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = upload(c->nodes, hs.nodes)) != hipSuccess) return bail(e, "upload nodes");
     if ((e = upload(c->nodes4, hs.nodes4)) != hipSuccess) return bail(e, "upload nodes4");
     if ((e = upload(c->nodes8, hs.nodes8)) != hipSuccess) return bail(e, "upload nodes8");
@@ -243,73 +309,50 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if ((e = upload(c->lights, hs.lights)) != hipSuccess) return bail(e, "upload lights");
     if ((e = upload(c->light_pos64, hs.light_pos64)) != hipSuccess) return bail(e, "upload light corners");
     if ((e = upload(c->texels, hs.texels)) != hipSuccess) return bail(e, "upload texels");
-    const size_t accum_bytes = size_t(c->width) * c->height * sizeof(float4);
-    if ((e = c->accum_own.alloc(accum_bytes)) != hipSuccess) return bail(e, "alloc accumulator");
-    if ((e = hipMemset(c->accum_own.p, 0, accum_bytes)) != hipSuccess) return bail(e, "clear accumulator");
-    if ((e = c->counters.alloc(sizeof(DevCounters) * WF_COUNTER_REPLICAS)) != hipSuccess) return bail(e, "alloc counters");
-    if ((e = hipMemset(c->counters.p, 0, sizeof(DevCounters) * WF_COUNTER_REPLICAS)) != hipSuccess) return bail(e, "clear counters");
-    {   // ---- wavefront pool.  Tunables are developer knobs (environment), not part of the ABI.
-        hipDeviceProp_t prop;
-        if ((e = hipGetDeviceProperties(&prop, c->device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
-        c->n_cus = prop.multiProcessorCount;
-        const char* pipe = std::getenv("MCPT_PIPELINE");
-        c->use_wavefront = !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS;
-        c->pool_cap = 1u << std::min(26u, env_u32("MCPT_WF_POOL_LOG2", 23));
-        if (c->pool_cap < 2048) c->pool_cap = 2048;
-        c->items_per_slot = std::max(1u, env_u32("MCPT_WF_ITEMS_PER_SLOT", 1));
-        c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
-        c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0); c->tune.pend_cap = 48;      // speculative traversal: refined below once the scene's size is known
-        c->time_kernels = env_u32("MCPT_TIME_KERNELS", 0);
-        if (c->use_wavefront) {
-            uint32_t n_lanes = env_u32("MCPT_WF_LANES", 2);
-            if (n_lanes < 1) n_lanes = 1;
-            if (o.flags & MCPT_FLAG_DETERMINISTIC) n_lanes = 1;          // one owner per pixel, plain stores
-            // Persistent trace grid: one 1024-thread block (16 waves, 78 VGPRs) per CU -- what the register file admits beside two shade
-            // waves per SIMD (4 x 80 + 2 x 96 = 512).  Rounds 1-2 launched 3/4 and 7/8 of the CUs while the traversal data was
-            // cache-resident (their 72-register kernel left room for a second block on some CUs); r03, 8-wide kernel, S-cornell 512 spp:
-            // 214.6 / 217.5 / 211.6 / 213.4 / 208.5 ms at 192 / 208 / 224 / 240 / 256 blocks.  MCPT_WF_GRID overrides.
-            const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((o.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0, hs.bvh_width));
-            c->trace_grid = uint32_t(c->n_cus) * per_cu;
-            c->trace_grid = std::min(env_u32("MCPT_WF_GRID", c->trace_grid), uint32_t(c->n_cus) * per_cu);
-            // speculative traversal: S-cornell 469 -> 450 ms; on the 4 M-triangle configuration, where the extra node visits are HBM
-            // traffic, it is neutral within the noise (same box: 367 ms with, 371 ms without) -- on everywhere; MCPT_WF_PEND=0 turns it off
-            c->tune.pend_cap = env_u32("MCPT_WF_PEND", 48u);
-            if ((e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-            c->lanes.resize(n_lanes);
-            for (auto& L : c->lanes) {
-                L.pool.P = 0;                                             // allocated by ensure_pool() when the first job arrives
-                if ((e = L.ctl_buf.alloc(sizeof(IterCtl))) != hipSuccess) return bail(e, "alloc IterCtl");
-                if ((e = hipHostMalloc((void**)&L.h_ctl, 8 * sizeof(IterCtl), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
-                L.chk_ev.resize(8);
-                for (auto& ev : L.chk_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-                if ((e = hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-                if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-                if ((e = L.ovf_buf.alloc(size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_bytes_per_lane(hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth, hs.bvh_width))) != hipSuccess)
-                    return bail(e, "alloc stack overflow area");
-            }
-        }
-    }
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "sync after upload");
-    c->accum = static_cast<float4*>(c->accum_own.p);
-
     DevScene& d = c->dev;
-    d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes4 = static_cast<const float4*>(c->nodes4.p); d.n_nodes4 = int32_t(hs.nodes4.size() / 4); d.nodes8 = static_cast<const float4*>(c->nodes8.p); d.n_nodes8 = int32_t(hs.nodes8.size() / 5); d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
-    d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p); d.tri_plane64 = static_cast<const double*>(c->tri_plane64.p);
-    d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
-    d.lights = static_cast<const DevLight*>(c->lights.p); d.light_pos64 = static_cast<const double*>(c->light_pos64.p); d.texels = static_cast<const float4*>(c->texels.p);
+    d.n_nodes4 = int32_t(hs.nodes4.size() / 4); d.n_nodes8 = int32_t(hs.nodes8.size() / 5);
     d.cam = hs.cam;
     for (int a = 0; a < 3; a++) d.centre[a] = hs.centre[a];
     d.n_tris = int32_t(hs.tri_face.size()); d.n_lights = int32_t(hs.lights.size()); d.n_nodes = int32_t(hs.nodes.size() / 4); d.n_mats = int32_t(hs.mats.size());
-
-    c->binary_ok = hs.binary_ok;
     mcpt_scene_info& in = c->info;
     in.n_tris = uint32_t(d.n_tris); in.n_lights = uint32_t(d.n_lights); in.n_nodes = uint32_t(d.n_nodes);
     in.bvh_depth = hs.bvh_depth; in.max_leaf = hs.max_leaf; in.width = uint32_t(c->width); in.height = uint32_t(c->height);
-    in.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes + c->mats.bytes +
-                      c->lights.bytes + c->light_pos64.bytes + c->texels.bytes + accum_bytes;
     in.bvh_build_ms = hs.bvh_build_ms;
     fill_wide_info(in, hs);
+    const mcpt_status fs = finish_ctx(c);
+    if (fs != MCPT_OK) { destroy_ctx(c); return fs; }
     in.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out_ctx = c;
+    return MCPT_OK;
+}
+
+/* A second context for the SAME scene on another device (or the same one): every scene stream is copied device to device -- no flatten, no
+ * BVH build, no host copy of the scene is kept around for it.  `mcpt_cli --gpus N` builds once and clones N - 1 times. */
+mcpt_status mcpt_clone_to_device(mcpt_ctx* src, int32_t device, mcpt_ctx** out_ctx) {
+    if (!src || !out_ctx) return fail(MCPT_ERR_INVALID_ARG, "mcpt_clone_to_device: null argument");
+    *out_ctx = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(MCPT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(MCPT_ERR_NO_DEVICE, "device ordinal out of range");
+    mcpt_status st = use(src); if (st != MCPT_OK) return st;
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    mcpt_ctx* c = new mcpt_ctx();
+    c->device = device; c->opts = src->opts; c->opts.device = device; c->width = src->width; c->height = src->height;
+    c->wide_width = src->wide_width; c->wide_depth = src->wide_depth; c->binary_ok = src->binary_ok;
+    c->dev = src->dev; c->info = src->info; c->info.bvh_build_ms = 0.0;
+    auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    auto t0 = std::chrono::steady_clock::now();
+    DevBuf* from[12] = {&src->nodes, &src->nodes4, &src->nodes8, &src->tri_isect, &src->tri_shade, &src->tri_pos64, &src->tri_plane64, &src->tri_face, &src->mats, &src->lights, &src->light_pos64, &src->texels};
+    DevBuf* to[12] = {&c->nodes, &c->nodes4, &c->nodes8, &c->tri_isect, &c->tri_shade, &c->tri_pos64, &c->tri_plane64, &c->tri_face, &c->mats, &c->lights, &c->light_pos64, &c->texels};
+    for (int i = 0; i < 12; i++) {
+        if ((e = to[i]->alloc(from[i]->bytes)) != hipSuccess) return bail(e, "alloc scene stream");
+        if (from[i]->bytes && (e = hipMemcpyPeer(to[i]->p, device, from[i]->p, src->device, from[i]->bytes)) != hipSuccess) return bail(e, "hipMemcpyPeer");
+    }
+    const mcpt_status fs = finish_ctx(c);
+    if (fs != MCPT_OK) { destroy_ctx(c); return fs; }
+    c->info.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out_ctx = c;
     return MCPT_OK;
 }
@@ -616,6 +659,20 @@ mcpt_status mcpt_tonemap(mcpt_ctx* ctx, uint8_t* rgb_host, int flip_y) {
     Scratch s; uint8_t* d_rgb = nullptr;
     HIP_TRY(s.out(3 * n, &d_rgb));
     HIP_TRY(launch_tonemap(ctx->accum, d_rgb, ctx->width, ctx->height, flip_y, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(rgb_host, d_rgb, 3 * n, hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
+/* Scene::getPixelsColor of ANY film of this context's size that lives on its device -- e.g. the sum of several devices' films, reduced
+ * into a scratch buffer for a progressive image of a multi-GPU render (mcpt_cli --gpus N --save-every K). */
+mcpt_status mcpt_tonemap_buffer(mcpt_ctx* ctx, const void* device_rgba, uint8_t* rgb_host, int flip_y) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!rgb_host || !device_rgba) return fail(MCPT_ERR_INVALID_ARG, "null argument");
+    const size_t n = size_t(ctx->width) * ctx->height;
+    Scratch s; uint8_t* d_rgb = nullptr;
+    HIP_TRY(s.out(3 * n, &d_rgb));
+    HIP_TRY(launch_tonemap(static_cast<const float4*>(device_rgba), d_rgb, ctx->width, ctx->height, flip_y, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(rgb_host, d_rgb, 3 * n, hipMemcpyDeviceToHost));
     return MCPT_OK;

@@ -37,6 +37,11 @@ void Render::create(Model& m, const mcpt_opts& opts) {
 }
 Render::Render(Model& m) { mcpt_opts o; std::memset(&o, 0, sizeof o); o.struct_size = sizeof o; create(m, o); }
 Render::Render(Model& m, const mcpt_opts& opts) { create(m, opts); }
+Render::Render(Render& other, int device) {
+    seed = other.seed;
+    if (!other.ctx || mcpt_clone_to_device(other.ctx, device, &ctx) != MCPT_OK) { std::cerr << "Error: mcpt_clone_to_device: " << mcpt_last_error() << std::endl; ctx = nullptr; return; }
+    film.resize(other.film.size());
+}
 Render::~Render() {
     if (target) { flush_into(*target); target->detach(this); }
     if (ctx) mcpt_destroy(ctx);

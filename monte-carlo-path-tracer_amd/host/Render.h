@@ -10,6 +10,7 @@ class Render : public FilmSource {
 public:
     explicit Render(Model& m_model);                  // Render.cpp:5-10: flatten + BVH + upload (inside mcpt_create)
     Render(Model& m_model, const mcpt_opts& opts);
+    Render(Render& same_scene, int device);           // the same scene on another GPU: copied device to device, nothing is built again
     ~Render();
     void render(Scene& scene);                        // Render.cpp:56-69: adds exactly ONE sample to every pixel of `scene`
     void render(Scene& scene, uint32_t spp);          // the same `spp` times in one call

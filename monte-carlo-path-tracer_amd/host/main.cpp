@@ -95,10 +95,14 @@ int main(int argc, char** argv) {
     if (batch == 0) batch = spp;
     if (gpus < 1) gpus = 1;
 
+    // The scene is flattened and its BVH built ONCE (Render::Render(Model&), Render.cpp:5-10); the other devices get device-to-device
+    // copies of the finished streams (mcpt_clone_to_device): 8 GPUs cost one build + 8 uploads, not 8 builds.
     std::vector<Render*> renders(gpus, nullptr);
     for (uint32_t g = 0; g < gpus; g++) {
-        mcpt_opts o; std::memset(&o, 0, sizeof o); o.struct_size = sizeof o; o.device = int32_t(g); o.max_depth = depth; o.flags = flags; o.integrator = integrator;
-        renders[g] = new Render(model, o); renders[g]->seed = seed;
+        if (g == 0) {
+            mcpt_opts o; std::memset(&o, 0, sizeof o); o.struct_size = sizeof o; o.device = 0; o.max_depth = depth; o.flags = flags; o.integrator = integrator;
+            renders[0] = new Render(model, o); renders[0]->seed = seed;
+        } else renders[g] = new Render(*renders[0], int(g));
         if (!renders[g]->ok()) return 1;
     }
     std::vector<ncclComm_t> comms(gpus);
@@ -107,6 +111,7 @@ int main(int argc, char** argv) {
         if (ncclCommInitAll(comms.data(), int(gpus), devs.data()) != ncclSuccess) { std::cerr << "Error: ncclCommInitAll" << std::endl; return 1; }
     }
     uint32_t frame = 0, batches_done = 0; uint64_t rays = 0; double total_s = 0;
+    void* progress_film = nullptr;                    // device 0: the sum of all devices' films, for --save-every with several devices
     std::vector<float> film(size_t(w) * h * 4);
     std::atomic<int> failed{0};                       // any device error or failed collective: no image, non-zero exit
     auto fail_with = [&](const std::string& what) { std::cerr << "Error: " << what << std::endl; failed.store(1); };
@@ -137,12 +142,27 @@ int main(int argc, char** argv) {
         total_s += s; frame += n;
         std::cout << "frame: " << frame << "    frame cost: " << s << "s\n";                       // main.cpp:31
         // --save-every K: a progressive image every K batches, like the reference's window shows every frame (main.cpp:33-36) -- tonemapped
-        // on the device (Scene::getPixelsColor as a kernel: mean, clamp, sqrt, x255.99) from device 0's film, 3 bytes per pixel read back;
-        // with several devices that is the image of device 0's share of the samples so far
+        // on the device (Scene::getPixelsColor as a kernel: mean, clamp, sqrt, x255.99), 3 bytes per pixel read back
         batches_done++;
         if (save_every && batches_done % save_every == 0 && frame < spp) {
             std::vector<uint8_t> rgb(size_t(w) * h * 3);
-            if (mcpt_tonemap(renders[0]->handle(), rgb.data(), 1) != MCPT_OK) { fail_with(std::string("mcpt_tonemap: ") + mcpt_last_error()); break; }
+            bool ok_img;
+            if (gpus == 1) ok_img = mcpt_tonemap(renders[0]->handle(), rgb.data(), 1) == MCPT_OK;
+            else {
+                // the whole film so far, like the reference's window (main.cpp:26-36): the devices' films are summed into a scratch film on
+                // device 0 (ncclReduce; the films themselves keep accumulating untouched) and that one is tonemapped
+                bool ok = hipSetDevice(0) == hipSuccess && (progress_film || hipMalloc(&progress_film, size_t(w) * h * 16) == hipSuccess);
+                ok = ok && ncclGroupStart() == ncclSuccess;
+                for (uint32_t g = 0; g < gpus && ok; g++) {
+                    void* p = nullptr;
+                    ok = mcpt_accum_device_ptr(renders[g]->handle(), &p) == MCPT_OK && hipSetDevice(int(g)) == hipSuccess &&
+                         ncclReduce(p, progress_film, size_t(w) * h * 4, ncclFloat, ncclSum, 0, comms[g], nullptr) == ncclSuccess;
+                }
+                ok = (ncclGroupEnd() == ncclSuccess) && ok;
+                for (uint32_t g = 0; g < gpus && ok; g++) ok = hipSetDevice(int(g)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                ok_img = ok && mcpt_tonemap_buffer(renders[0]->handle(), progress_film, rgb.data(), 1) == MCPT_OK;
+            }
+            if (!ok_img) { fail_with(std::string("progressive image: ") + mcpt_last_error()); break; }
             const std::string file = out + std::to_string(frame) + ".png";
             if (write_png_rgb8(file, w, h, rgb.data())) std::cout << "Image saved successfully: " << file << std::endl;
             else std::cerr << "Failed to save image: " << file << std::endl;
@@ -167,6 +187,7 @@ int main(int argc, char** argv) {
         }
         total_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    if (progress_film) { (void)hipSetDevice(0); (void)hipFree(progress_film); }
     if (gpus > 1) for (auto& c : comms) (void)ncclCommDestroy(c);
     if (failed.load()) { for (auto r : renders) delete r; return 1; }
     for (uint32_t g = 0; g < gpus; g++) {

@@ -630,6 +630,11 @@ def test_cpp_cli_multi_gpu_path_or_its_failure(pkg, tmp_path):
         assert (np.abs(a - b) <= 1).mean() > 0.999
         subprocess.check_call(base + ["--gpus", "2", "--shard", "tiles", "--out", str(tmp_path / "two_tiles")], stdout=subprocess.DEVNULL)
         assert np.array_equal(one, np.asarray(Image.open(str(tmp_path / "two_tiles8.png"))))   # disjoint tiles: no summation-order effect at all
+        # --save-every with two devices shows the WHOLE film so far (ncclReduce into a scratch film on device 0), like the reference's window
+        subprocess.check_call(base + ["--gpus", "1", "--batch", "4", "--save-every", "1", "--out", str(tmp_path / "p1")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(base + ["--gpus", "2", "--batch", "4", "--save-every", "1", "--out", str(tmp_path / "p2")], stdout=subprocess.DEVNULL)
+        h1 = np.asarray(Image.open(str(tmp_path / "p14.png"))).astype(int); h2 = np.asarray(Image.open(str(tmp_path / "p24.png"))).astype(int)
+        assert (np.abs(h1 - h2) <= 1).mean() > 0.999
     else:
         assert p2.returncode != 0 and "Error" in p2.stderr
         assert not os.path.exists(str(tmp_path / "two8.png"))
@@ -1154,3 +1159,23 @@ def test_c1_own_size_vs_oracle(pkg, orc):
     print("C1 256x256x16 spp depth 4: pixels beyond tolerance %.3f %%" % (100 * frac))
     assert frac <= 0.001
     assert abs(c.rays - (oc["rays_primary"] + oc["rays_continuation"] + oc["rays_shadow"])) <= 0.01 * c.rays
+
+
+def test_clone_to_device_shares_nothing_but_the_scene(pkg):
+    """mcpt_clone_to_device (what `mcpt_cli --gpus N` uses for devices 1 .. N-1; here onto the same device): the clone renders the same
+    film bit for bit (deterministic mode) without a BVH build of its own, and the two contexts' films, counters and streams are independent.
+    mcpt_tonemap_buffer of a context's own film is mcpt_tonemap."""
+    scene = pkg.scenes.cornell_box_small(48, 40)
+    a = pkg.Renderer(scene, max_depth=5, flags=pkg.FLAG_DETERMINISTIC)
+    b = a.clone(0)
+    ia, ib = a.info(), b.info()
+    assert (ib.n_tris, ib.n_nodes, ib.wide_nodes, ib.wide_depth, ib.bvh_depth) == (ia.n_tris, ia.n_nodes, ia.wide_nodes, ia.wide_depth, ia.bvh_depth) and ib.bvh_build_ms == 0.0
+    a.render(8, seed=9); fa = a.read_accum()
+    assert np.all(b.read_accum() == 0)                                     # the clone's film is its own
+    b.render(8, seed=9); fb = b.read_accum()
+    assert np.array_equal(fa, fb)
+    assert b.counters().paths == 48 * 40 * 8 and a.counters().paths == 48 * 40 * 8
+    assert np.array_equal(a.tonemap(), a.tonemap_buffer(a.accum_device_ptr()))
+    a.close()
+    b.render(8, seed=9, first_sample=8); assert np.all(b.read_accum()[..., 3] == 16)       # the clone outlives its source
+    b.close()
