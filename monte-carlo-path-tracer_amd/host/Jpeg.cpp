@@ -1,10 +1,11 @@
-// Baseline JPEG decoder for map_Kd textures (the reference reads them through stb_image's stbi_loadf, model.cpp:8-23; stb is a
-// third-party dependency that is not part of this build).  Written from ITU-T T.81: sequential DCT (SOF0 / SOF1), 8-bit samples,
-// Huffman coding, 1 or 3 components, sampling factors 1 and 2 in either direction, restart intervals, JFIF (YCbCr) and Adobe
+// JPEG decoder (baseline and progressive) for map_Kd textures (the reference reads them through stb_image's stbi_loadf, model.cpp:8-23; stb is a
+// third-party dependency that is not part of this build).  Written from ITU-T T.81: sequential DCT (SOF0 / SOF1) and progressive DCT
+// (SOF2: spectral selection + successive approximation, Annex G -- coefficients are collected over all scans, then transformed), 8-bit
+// samples, Huffman coding, 1 or 3 components, sampling factors 1 and 2 in either direction, restart intervals, JFIF (YCbCr) and Adobe
 // (RGB / YCbCr) colour conventions.  Chroma is upsampled with the triangle ("fancy") filter every common decoder uses, the inverse
 // DCT is evaluated in floating point: decoded bytes agree with libjpeg-turbo to within 3 of 255, 0.35 on average
 // (tests/test_abi_and_host.py; integer-IDCT decoders such as stb_image differ from each other by the same amount).
-// Progressive (SOF2) and arithmetic-coded files are rejected -- the caller reports the texture as unreadable.
+// Lossless, hierarchical and arithmetic-coded files are rejected -- the caller reports the texture as unreadable.
 #include "Jpeg.h"
 
 #include <cmath>
@@ -40,6 +41,7 @@ struct Component {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
     int pw = 0, ph = 0;                       // plane size, padded to whole MCUs
     std::vector<unsigned char> plane;
+    std::vector<short> coef;                  // progressive: 64 coefficients per block (natural order), blocks in plane raster (pw / 8 per row)
 };
 
 class Decoder {
@@ -51,16 +53,22 @@ public:
         for (;;) {
             int m = next_marker();
             if (m < 0) return false;
-            if (m == 0xD9) return false;                              // EOI before any scan
+            if (m == 0xD9) { if (!progressive_ || !scans_) return false; break; }   // EOI: a progressive file ends here; before any scan it is an error
             if (m == 0xC0 || m == 0xC1) { if (!read_sof()) return false; }
-            else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) return false;   // progressive / lossless / arithmetic
+            else if (m == 0xC2) { progressive_ = true; if (!read_sof()) return false; }
+            else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) return false;   // lossless / hierarchical / arithmetic
             else if (m == 0xC4) { if (!read_dht()) return false; }
             else if (m == 0xDB) { if (!read_dqt()) return false; }
             else if (m == 0xDD) { if (!read_dri()) return false; }
             else if (m == 0xEE) { if (!read_adobe()) return false; }
-            else if (m == 0xDA) { if (!read_sos() || !decode_scan()) return false; break; }   // baseline: one interleaved scan
+            else if (m == 0xDA) {
+                if (!progressive_) { if (!read_sos() || !decode_scan()) return false; break; }   // baseline: one interleaved scan
+                if (!read_sos_progressive() || !decode_scan_progressive()) return false;
+                if (++scans_ > 1000) return false;                     // (a crafted file could go on for ever)
+            }
             else if (!skip_segment()) return false;
         }
+        if (progressive_ && !finish_progressive()) return false;
         w = width_; h = height_;
         return to_rgb(rgb);
     }
@@ -69,6 +77,8 @@ private:
     const unsigned char* d_; size_t n_, pos_ = 0;
     int width_ = 0, height_ = 0, ncomp_ = 0, hmax_ = 1, vmax_ = 1, restart_ = 0;
     bool adobe_ = false; int adobe_transform_ = 0;
+    bool progressive_ = false; int scans_ = 0;
+    int scan_n_ = 0, scan_comp_[3] = {0, 0, 0}, ss_ = 0, se_ = 0, ah_ = 0, al_ = 0, eobrun_ = 0;   // the current progressive scan
     unsigned short qt_[4][64] = {};
     bool qt_defined_[4] = {false, false, false, false};
     Huffman dc_[4], ac_[4];
@@ -144,6 +154,7 @@ private:
             Component& c = comp_[i];
             c.pw = mcux * c.h * 8; c.ph = mcuy * c.v * 8;
             c.plane.assign(size_t(c.pw) * size_t(c.ph), 0);
+            if (progressive_) c.coef.assign(size_t(c.pw) * size_t(c.ph), 0);
         }
         return true;
     }
@@ -257,6 +268,137 @@ private:
                 }
                 if (restart_) until_restart--;
             }
+        return true;
+    }
+
+
+    // ---- progressive mode (T.81 Annex G)
+    bool read_sos_progressive() {
+        size_t b, e; if (!segment(b, e) || width_ == 0 || e - b < 1) return false;
+        const int ns = d_[b];
+        if (ns < 1 || ns > ncomp_ || e - b < size_t(1 + 2 * ns + 3)) return false;
+        scan_n_ = ns;
+        for (int i = 0; i < ns; i++) {
+            const int id = d_[b + 1 + 2 * size_t(i)], t = d_[b + 2 + 2 * size_t(i)];
+            int k = -1; for (int j = 0; j < ncomp_; j++) if (comp_[j].id == id) k = j;
+            if (k < 0 || (i && k <= scan_comp_[i - 1])) return false;     // known components, in frame order
+            scan_comp_[i] = k; comp_[k].td = t >> 4; comp_[k].ta = t & 15;
+            if (comp_[k].td > 3 || comp_[k].ta > 3) return false;
+        }
+        ss_ = d_[b + 1 + 2 * size_t(ns)]; se_ = d_[b + 2 + 2 * size_t(ns)]; ah_ = d_[b + 3 + 2 * size_t(ns)] >> 4; al_ = d_[b + 3 + 2 * size_t(ns)] & 15;
+        if (ss_ > se_ || se_ > 63 || al_ > 13 || ah_ > 13 || (ss_ == 0 && se_ != 0) || (ss_ > 0 && ns != 1)) return false;   // DC scans carry DC only; AC scans one component
+        for (int i = 0; i < ns; i++) {
+            const Component& c = comp_[scan_comp_[i]];
+            if (ss_ == 0 ? (ah_ == 0 && !dc_[c.td].defined) : !ac_[c.ta].defined) return false;
+        }
+        return true;
+    }
+    int get_bit() { return get_bits(1); }
+    bool dc_first(Component& c, short* blk) {
+        const int t = decode_symbol(dc_[c.td]);
+        if (t < 0 || t > 11) return false;
+        c.pred += extend(get_bits(t), t);
+        if (c.pred < -32768 || c.pred > 32767) return false;
+        blk[0] = short(c.pred * (1 << al_));
+        return true;
+    }
+    void dc_refine(short* blk) { if (get_bit()) blk[0] = short(blk[0] | (1 << al_)); }
+    bool ac_first(const Component& c, short* blk) {
+        if (eobrun_ > 0) { eobrun_--; return true; }
+        for (int k = ss_; k <= se_;) {
+            const int rs = decode_symbol(ac_[c.ta]);
+            if (rs < 0) return false;
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+                if (r < 15) { eobrun_ = (1 << r) - 1; if (r) eobrun_ += get_bits(r); break; }   // EOBn: this block and eobrun_ more end here
+                k += 16; continue;                                                               // ZRL
+            }
+            k += r;
+            if (k > se_) return false;
+            blk[kZigzag[k]] = short(extend(get_bits(sz), sz) * (1 << al_));
+            k++;
+        }
+        return true;
+    }
+    // G.1.2.3: a refinement scan sends one more bit of every coefficient that is already non-zero (a correction bit) and the newly
+    // non-zero ones (magnitude 1 << al_) in between, with zero runs that count only coefficients that are still zero
+    void correct(short& v) { if (get_bit() && (v & (1 << al_)) == 0) v = short(v > 0 ? v + (1 << al_) : v - (1 << al_)); }
+    bool ac_refine(const Component& c, short* blk) {
+        int k = ss_;
+        if (eobrun_ > 0) { eobrun_--; for (; k <= se_; k++) { short& v = blk[kZigzag[k]]; if (v != 0) correct(v); } return true; }
+        while (k <= se_) {
+            const int rs = decode_symbol(ac_[c.ta]);
+            if (rs < 0) return false;
+            int r = rs >> 4; const int sz = rs & 15; int nv = 0;
+            if (sz == 0) {
+                if (r < 15) { eobrun_ = (1 << r) - 1; if (r) eobrun_ += get_bits(r); r = 64; }   // end of band for this block: corrections for the rest of it
+            } else {
+                if (sz != 1) return false;
+                nv = get_bit() ? (1 << al_) : -(1 << al_);
+            }
+            while (k <= se_) {
+                short& v = blk[kZigzag[k++]];
+                if (v != 0) correct(v);
+                else { if (r == 0) { if (nv) v = short(nv); break; } r--; }
+            }
+        }
+        return true;
+    }
+    bool decode_scan_progressive() {
+        bitbuf_ = 0; bitcnt_ = 0; hit_marker_ = false; eobrun_ = 0;
+        for (int i = 0; i < ncomp_; i++) comp_[i].pred = 0;
+        int until_restart = restart_;
+        auto block_of = [](Component& c, int bx, int by) { return &c.coef[(size_t(by) * size_t(c.pw / 8) + size_t(bx)) * 64]; };
+        auto one = [&](Component& c, short* blk) -> bool {
+            if (ss_ == 0) { if (ah_ == 0) return dc_first(c, blk); dc_refine(blk); return true; }
+            return ah_ == 0 ? ac_first(c, blk) : ac_refine(c, blk);
+        };
+        auto at_restart = [&]() { if (restart_ && until_restart == 0) { restart(); eobrun_ = 0; until_restart = restart_; } };
+        if (scan_n_ == 1) {                                               // non-interleaved: the component's own blocks in raster order (A.2.3)
+            Component& c = comp_[scan_comp_[0]];
+            const int cw = (width_ * c.h + hmax_ - 1) / hmax_, chh = (height_ * c.v + vmax_ - 1) / vmax_;
+            const int bw = (cw + 7) / 8, bh = (chh + 7) / 8;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    at_restart();
+                    if (!one(c, block_of(c, bx, by))) return false;
+                    if (restart_) until_restart--;
+                }
+        } else {                                                          // interleaved (DC scans only): MCU order
+            const int mcux = (width_ + 8 * hmax_ - 1) / (8 * hmax_), mcuy = (height_ + 8 * vmax_ - 1) / (8 * vmax_);
+            for (int my = 0; my < mcuy; my++)
+                for (int mx = 0; mx < mcux; mx++) {
+                    at_restart();
+                    for (int i = 0; i < scan_n_; i++) {
+                        Component& c = comp_[scan_comp_[i]];
+                        for (int by = 0; by < c.v; by++)
+                            for (int bx = 0; bx < c.h; bx++)
+                                if (!one(c, block_of(c, mx * c.h + bx, my * c.v + by))) return false;
+                    }
+                    if (restart_) until_restart--;
+                }
+        }
+        return true;
+    }
+    bool finish_progressive() {                                           // dequantise + inverse DCT of every block, once all scans are in
+        float px[64]; int coef[64];
+        for (int i = 0; i < ncomp_; i++) {
+            Component& c = comp_[i];
+            if (!qt_defined_[c.tq]) return false;
+            const int bw = c.pw / 8, bh = c.ph / 8;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    const short* blk = &c.coef[(size_t(by) * size_t(bw) + size_t(bx)) * 64];
+                    for (int k = 0; k < 64; k++) coef[k] = int(blk[k]) * qt_[c.tq][k];
+                    idct(coef, px);
+                    unsigned char* dst = &c.plane[size_t(by * 8) * size_t(c.pw) + size_t(bx * 8)];
+                    for (int y = 0; y < 8; y++)
+                        for (int x = 0; x < 8; x++) {
+                            const float v = px[8 * y + x] + 128.0f;
+                            dst[size_t(y) * size_t(c.pw) + size_t(x)] = (unsigned char)(v <= 0.f ? 0 : (v >= 255.f ? 255 : int(v + 0.5f)));
+                        }
+                }
+        }
         return true;
     }
 

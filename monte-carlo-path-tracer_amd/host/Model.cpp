@@ -38,7 +38,7 @@ template <class Bytes> Bytes read_file(const std::string& filename) {
 }
 bool starts(const std::string& s, const char* t) { return s.compare(0, std::strlen(t), t) == 0; }
 
-// ---- PNG via zlib: every colour type (grey, RGB, palette, grey+alpha, RGBA), bit depths 1-16, non-interlaced; returns RGB bytes
+// ---- PNG via zlib: every colour type (grey, RGB, palette, grey+alpha, RGBA), bit depths 1-16, plain or Adam7-interlaced; returns RGB bytes
 //      (16-bit samples keep their high byte, alpha is dropped -- what stb_image's 8-bit RGB request does)
 uint32_t be32(const unsigned char* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
 bool load_png(const std::vector<unsigned char>& f, int& w, int& h, std::vector<unsigned char>& rgb) {
@@ -57,42 +57,115 @@ bool load_png(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
                           ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
-    if (ch == 0 || !depth_ok || interlace != 0 || w <= 0 || h <= 0 || size_t(w) * size_t(h) > (size_t(1) << 28) || (ctype == 3 && plte.size() < 3)) return false;
+    if (ch == 0 || !depth_ok || interlace > 1 || w <= 0 || h <= 0 || size_t(w) * size_t(h) > (size_t(1) << 28) || (ctype == 3 && plte.size() < 3)) return false;
     const size_t bpp = std::max<size_t>(1, size_t(ch) * depth / 8);            // filter distance in bytes
-    const size_t stride = (size_t(w) * ch * depth + 7) / 8;
-    std::vector<unsigned char> raw((stride + 1) * h);
+    // One pass = one filtered sub-image.  A non-interlaced file has a single pass (every pixel); an Adam7 file (PNG spec section 8.2) has
+    // seven, pass p holding the pixels (x0 + i dx, y0 + j dy) -- each with its own scanlines, filter bytes and row padding.
+    struct Pass { int x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const int n_pass = interlace ? 7 : 1;
+    size_t raw_size = 0;
+    for (int k = 0; k < n_pass; k++) {
+        const Pass& ps = interlace ? adam7[k] : whole;
+        const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw > 0 && ph > 0) raw_size += (((size_t(pw) * ch * depth + 7) / 8) + 1) * size_t(ph);
+    }
+    std::vector<unsigned char> raw(raw_size);
     uLongf out = uLongf(raw.size());
     if (uncompress(raw.data(), &out, idat.data(), uLong(idat.size())) != Z_OK || out != raw.size()) return false;
-    std::vector<unsigned char> img(stride * h);
-    for (int y = 0; y < h; y++) {
-        const unsigned char ft = raw[y * (stride + 1)]; const unsigned char* s = &raw[y * (stride + 1) + 1];
-        unsigned char* d = &img[y * stride]; const unsigned char* up = y ? &img[(y - 1) * stride] : nullptr;
-        for (size_t i = 0; i < stride; i++) {
-            int a = i >= bpp ? d[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, v = s[i];
-            switch (ft) {
-                case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
-                case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-                default: break;
-            }
-            d[i] = (unsigned char)v;
-        }
-    }
     rgb.resize(size_t(w) * h * 3);
     const int maxv = (1 << (depth < 8 ? depth : 8)) - 1;
-    for (int y = 0; y < h; y++) {
-        const unsigned char* row = &img[size_t(y) * stride];
-        for (int x = 0; x < w; x++) {
-            unsigned char* o = &rgb[3 * (size_t(y) * w + x)];
-            auto sample = [&](int k) -> int {                                      // k-th channel of pixel x, 8 significant bits
-                if (depth == 16) return row[2 * (size_t(x) * ch + k)];
-                if (depth == 8) return row[size_t(x) * ch + k];
-                const size_t bit = size_t(x) * depth; return (row[bit >> 3] >> (8 - depth - int(bit & 7))) & maxv;
-            };
-            if (ctype == 3) { const size_t i = size_t(sample(0)); const unsigned char* p = 3 * i + 2 < plte.size() ? &plte[3 * i] : &plte[0]; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
-            else if (ch <= 2) { int g = sample(0); if (depth < 8) g = g * 255 / maxv; o[0] = o[1] = o[2] = (unsigned char)g; }
-            else { o[0] = (unsigned char)sample(0); o[1] = (unsigned char)sample(1); o[2] = (unsigned char)sample(2); }
+    size_t rp = 0;
+    std::vector<unsigned char> img;
+    for (int k = 0; k < n_pass; k++) {
+        const Pass& ps = interlace ? adam7[k] : whole;
+        const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = (size_t(pw) * ch * depth + 7) / 8;
+        img.assign(stride * size_t(ph), 0);
+        for (int y = 0; y < ph; y++) {
+            const unsigned char ft = raw[rp]; const unsigned char* s = &raw[rp + 1]; rp += stride + 1;
+            unsigned char* d = &img[size_t(y) * stride]; const unsigned char* up = y ? &img[size_t(y - 1) * stride] : nullptr;
+            for (size_t i = 0; i < stride; i++) {
+                int a = i >= bpp ? d[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, v = s[i];
+                switch (ft) {
+                    case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
+                    case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                    default: break;
+                }
+                d[i] = (unsigned char)v;
+            }
+        }
+        for (int y = 0; y < ph; y++) {
+            const unsigned char* row = &img[size_t(y) * stride];
+            for (int x = 0; x < pw; x++) {
+                unsigned char* o = &rgb[3 * (size_t(ps.y0 + y * ps.dy) * w + size_t(ps.x0 + x * ps.dx))];
+                auto sample = [&](int kk) -> int {                                     // kk-th channel of pixel x, 8 significant bits
+                    if (depth == 16) return row[2 * (size_t(x) * ch + kk)];
+                    if (depth == 8) return row[size_t(x) * ch + kk];
+                    const size_t bit = size_t(x) * depth; return (row[bit >> 3] >> (8 - depth - int(bit & 7))) & maxv;
+                };
+                if (ctype == 3) { const size_t i = size_t(sample(0)); const unsigned char* p = 3 * i + 2 < plte.size() ? &plte[3 * i] : &plte[0]; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+                else if (ch <= 2) { int g = sample(0); if (depth < 8) g = g * 255 / maxv; o[0] = o[1] = o[2] = (unsigned char)g; }
+                else { o[0] = (unsigned char)sample(0); o[1] = (unsigned char)sample(1); o[2] = (unsigned char)sample(2); }
+            }
         }
     }
+    return true;
+}
+// ---- BMP (BITMAPINFOHEADER and later, uncompressed): 8-bit palettised, 24- and 32-bit true colour; bottom-up or top-down rows
+bool load_bmp(const std::vector<unsigned char>& f, int& w, int& h, std::vector<unsigned char>& rgb) {
+    auto le16 = [&](size_t p) { return int(f[p]) | (int(f[p + 1]) << 8); };
+    auto le32 = [&](size_t p) { return int32_t(uint32_t(f[p]) | (uint32_t(f[p + 1]) << 8) | (uint32_t(f[p + 2]) << 16) | (uint32_t(f[p + 3]) << 24)); };
+    if (f.size() < 54 || f[0] != 'B' || f[1] != 'M') return false;
+    const size_t off = size_t(uint32_t(le32(10))); const int hdr = le32(14);
+    if (hdr < 40) return false;
+    w = le32(18); int hh = le32(22); const int planes = le16(26), bpp = le16(28), comp = le32(30);
+    const bool top_down = hh < 0; h = top_down ? -hh : hh;
+    if (w <= 0 || h <= 0 || planes != 1 || (comp != 0 && !(comp == 3 && bpp == 32)) || (bpp != 8 && bpp != 24 && bpp != 32) || size_t(w) * size_t(h) > (size_t(1) << 28)) return false;
+    const size_t stride = ((size_t(w) * bpp + 31) / 32) * 4;
+    if (off + stride * size_t(h) > f.size()) return false;
+    const size_t pal = 14 + size_t(hdr); int ncol = le32(46); if (ncol == 0) ncol = 256;
+    if (bpp == 8 && pal + 4 * size_t(ncol) > f.size()) return false;
+    rgb.resize(size_t(w) * h * 3);
+    for (int y = 0; y < h; y++) {
+        const unsigned char* row = &f[off + stride * size_t(top_down ? y : h - 1 - y)];
+        for (int x = 0; x < w; x++) {
+            unsigned char* o = &rgb[3 * (size_t(y) * w + x)];
+            if (bpp == 8) { const int i = row[x] < ncol ? row[x] : 0; const unsigned char* p = &f[pal + 4 * size_t(i)]; o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; }
+            else { const unsigned char* p = row + size_t(x) * (bpp / 8); o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; }
+        }
+    }
+    return true;
+}
+// ---- TGA: true colour (types 2 / 10, 24 or 32 bits) and grey (3 / 11, 8 bits), raw or run-length coded, either vertical orientation.
+//      No signature exists for this format: tried last, and only for a plausible header.
+bool load_tga(const std::vector<unsigned char>& f, int& w, int& h, std::vector<unsigned char>& rgb) {
+    if (f.size() < 18) return false;
+    const int idlen = f[0], cmap = f[1], type = f[2], bpp = f[16], desc = f[17];
+    w = int(f[12]) | (int(f[13]) << 8); h = int(f[14]) | (int(f[15]) << 8);
+    const bool grey = type == 3 || type == 11, rle = type == 10 || type == 11;
+    if (cmap != 0 || !(type == 2 || type == 3 || type == 10 || type == 11) || w <= 0 || h <= 0 || (grey ? bpp != 8 : (bpp != 24 && bpp != 32)) || (desc & 0xC0)) return false;
+    const size_t px = size_t(bpp / 8), n = size_t(w) * h;
+    std::vector<unsigned char> raw(n * px);
+    size_t pos = 18 + size_t(idlen), o = 0;
+    if (!rle) { if (pos + raw.size() > f.size()) return false; std::memcpy(raw.data(), &f[pos], raw.size()); }
+    else while (o < raw.size()) {
+        if (pos >= f.size()) return false;
+        const int c = f[pos++]; const size_t cnt = size_t(c & 127) + 1;
+        if (o + cnt * px > raw.size()) return false;
+        if (c & 128) { if (pos + px > f.size()) return false; for (size_t i = 0; i < cnt; i++) { std::memcpy(&raw[o], &f[pos], px); o += px; } pos += px; }
+        else { if (pos + cnt * px > f.size()) return false; std::memcpy(&raw[o], &f[pos], cnt * px); o += cnt * px; pos += cnt * px; }
+    }
+    rgb.resize(n * 3);
+    const bool top_down = (desc & 0x20) != 0, right_left = (desc & 0x10) != 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const unsigned char* p = &raw[(size_t(top_down ? y : h - 1 - y) * w + size_t(right_left ? w - 1 - x : x)) * px];
+            unsigned char* q = &rgb[3 * (size_t(y) * w + x)];
+            if (grey) q[0] = q[1] = q[2] = p[0]; else { q[0] = p[2]; q[1] = p[1]; q[2] = p[0]; }
+        }
     return true;
 }
 bool load_ppm(const std::vector<unsigned char>& f, int& w, int& h, std::vector<unsigned char>& rgb) {
@@ -116,13 +189,13 @@ bool load_ppm(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
 
 bool load_image_rgb8(const std::string& filename, int& w, int& h, std::vector<unsigned char>& rgb) {
     const std::vector<unsigned char> bytes = read_file<std::vector<unsigned char>>(filename);
-    return !bytes.empty() && (load_png(bytes, w, h, rgb) || load_jpeg(bytes, w, h, rgb) || load_ppm(bytes, w, h, rgb));
+    return !bytes.empty() && (load_png(bytes, w, h, rgb) || load_jpeg(bytes, w, h, rgb) || load_ppm(bytes, w, h, rgb) || load_bmp(bytes, w, h, rgb) || load_tga(bytes, w, h, rgb));
 }
 
 Texture::Texture(const std::string& filename) {
     std::vector<unsigned char> rgb; int w = 0, h = 0;
     if (!load_image_rgb8(filename, w, h, rgb)) {
-        std::cerr << "Error: cannot decode texture (non-interlaced PNG, baseline JPEG or binary PPM expected): " << filename << std::endl;
+        std::cerr << "Error: cannot decode texture (PNG, JPEG, binary PPM, uncompressed BMP or true-colour / grey TGA expected): " << filename << std::endl;
         ok = false; image_color.push_back(Color3f{0.5f, 0.5f, 0.5f}); return;
     }
     image_w = w; image_h = h;

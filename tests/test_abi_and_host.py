@@ -197,8 +197,9 @@ def test_cpp_host_loader_reads_the_reference_file_formats(pkg, tmp_path):
 
 
 def test_cpp_host_loader_decodes_jpeg_textures(pkg, tmp_path):
-    """host/Jpeg.cpp (baseline JPEG written from T.81) against libjpeg-turbo (Pillow): 4:4:4 / 4:2:2 / 4:2:0, odd sizes, grey,
-    restart intervals, optimised Huffman tables; progressive files are refused.  `mcpt_cli --decode-image` is host-only."""
+    """host/Jpeg.cpp (baseline and progressive JPEG written from T.81) against libjpeg-turbo (Pillow): 4:4:4 / 4:2:2 / 4:2:0, odd sizes,
+    grey, restart intervals, optimised Huffman tables; progressive files (spectral selection + successive approximation, the scan script
+    libjpeg writes) with and without restart intervals.  `mcpt_cli --decode-image` is host-only."""
     Image = pytest.importorskip("PIL.Image")
     cli = os.path.join(ROOT, "monte-carlo-path-tracer_amd", "csrc", "mcpt_cli")
     rng = np.random.RandomState(3)
@@ -214,18 +215,24 @@ def test_cpp_host_loader_decodes_jpeg_textures(pkg, tmp_path):
 
     cases = [("444", (64, 48), dict(quality=92, subsampling=0)), ("420", (67, 45), dict(quality=90, subsampling=2)),
              ("422", (130, 33), dict(quality=85, subsampling=1)), ("grey", (40, 40), dict(quality=90)),
-             ("rst", (100, 60), dict(quality=90, subsampling=2, restart_marker_blocks=3)), ("opt", (96, 96), dict(quality=95, subsampling=2, optimize=True))]
+             ("rst", (100, 60), dict(quality=90, subsampling=2, restart_marker_blocks=3)), ("opt", (96, 96), dict(quality=95, subsampling=2, optimize=True)),
+             ("p444", (64, 48), dict(quality=92, subsampling=0, progressive=True)), ("p420", (67, 45), dict(quality=90, subsampling=2, progressive=True)),
+             ("p422", (130, 33), dict(quality=75, subsampling=1, progressive=True)), ("pgrey", (41, 39), dict(quality=90, progressive=True)),
+             ("prst", (100, 60), dict(quality=90, subsampling=2, progressive=True, restart_marker_blocks=2)), ("plow", (97, 71), dict(quality=30, subsampling=2, progressive=True))]
     for name, (w, h), kw in cases:
         a = picture(w, h)
         jpg = str(tmp_path / (name + ".jpg")); out = str(tmp_path / (name + ".ppm"))
-        Image.fromarray(a[..., 0] if name == "grey" else a).save(jpg, **kw)
+        Image.fromarray(a[..., 0] if name.endswith("grey") else a).save(jpg, **kw)
+        if name.startswith("p"): assert b"\xff\xc2" in open(jpg, "rb").read()          # really a progressive (SOF2) file
         subprocess.check_call([cli, "--decode-image", jpg, out])
         mine = read_ppm(out).astype(int); ref = np.asarray(Image.open(jpg).convert("RGB")).astype(int)
         assert mine.shape == ref.shape
         d = np.abs(mine - ref)
         assert d.max() <= 3 and d.mean() <= 0.5, (name, d.max(), d.mean())
+    # arithmetic-coded / lossless files stay refused: a progressive file whose SOF2 marker is rewritten to SOF10 (progressive, arithmetic)
     Image.fromarray(picture(32, 32)).save(str(tmp_path / "p.jpg"), progressive=True)
-    assert subprocess.call([cli, "--decode-image", str(tmp_path / "p.jpg"), str(tmp_path / "p.ppm")], stderr=subprocess.DEVNULL) == 1
+    open(str(tmp_path / "a.jpg"), "wb").write(open(str(tmp_path / "p.jpg"), "rb").read().replace(b"\xff\xc2", b"\xff\xca", 1))
+    assert subprocess.call([cli, "--decode-image", str(tmp_path / "a.jpg"), str(tmp_path / "a.ppm")], stderr=subprocess.DEVNULL) == 1
     # and through the scene loader: a JPEG map_Kd ends up as (c/255)^2.2 texels (MTL: one `newmtl` block per material, in order)
     import json
     s = pkg.scenes.bathroom_stress(32, 18, detail=4, tex_size=16)
@@ -263,3 +270,58 @@ def test_cpp_host_loader_decodes_every_png_flavour(pkg, tmp_path):
         mine = np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
         want = np.repeat(a[..., :1], 3, axis=2) if k == "g16" else np.asarray(Image.open(src).convert("RGB"))   # 16-bit: high byte
         assert np.array_equal(mine, want), k
+
+
+def _adam7_png(img, depth=8):
+    """An Adam7-interlaced PNG of an (h, w[, c]) uint8 / uint16 array, written here (Pillow cannot write interlaced files): seven passes,
+    filter type 0 rows, one zlib stream -- PNG specification sections 8.2 and 9."""
+    import struct, zlib
+    a = np.asarray(img); h, w = a.shape[:2]; c = 1 if a.ndim == 2 else a.shape[2]
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    a = a.reshape(h, w, c)
+    raw = b""
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = a[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0: continue
+        for row in sub:
+            if depth == 16: body = row.astype(">u2").tobytes()
+            elif depth == 8: body = row.astype(np.uint8).tobytes()
+            else: body = np.packbits(np.unpackbits(row.astype(np.uint8).reshape(-1, 1), axis=1)[:, 8 - depth:].reshape(-1)).tobytes()   # depth 1, 2, 4: grey only
+            raw += b"\0" + body
+    def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+
+
+def test_cpp_host_loader_decodes_interlaced_png_bmp_and_tga(pkg, tmp_path):
+    """The other containers stbi_loadf reads for the reference (model.cpp:8-23) that real scene folders may hold: Adam7-interlaced PNG
+    (RGB, RGBA, grey, 16-bit, 4-bit grey; odd sizes down to 1 x 1 so that some passes are empty), BMP (24-bit, 8-bit palettised) and TGA
+    (true colour and grey, raw and run-length coded) -- exact against Pillow's decode of the same files."""
+    Image = pytest.importorskip("PIL.Image")
+    cli = os.path.join(ROOT, "monte-carlo-path-tracer_amd", "csrc", "mcpt_cli")
+    rng = np.random.RandomState(9)
+
+    def decoded(path):
+        out = path + ".ppm"
+        subprocess.check_call([cli, "--decode-image", path, out])
+        d = open(out, "rb").read(); parts = d.split(b"\n", 3); w, h = map(int, parts[1].split())
+        return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
+
+    for name, shape, depth in (("rgb", (37, 53, 3), 8), ("rgba", (9, 20, 4), 8), ("grey", (33, 31), 8), ("g16", (17, 19), 16), ("g4", (21, 13), 4),
+                               ("one", (1, 1, 3), 8), ("thin", (1, 5, 3), 8), ("tall", (7, 1, 3), 8), ("rgb16", (12, 11, 3), 16)):
+        hi = 65536 if depth == 16 else (1 << depth)
+        a = rng.randint(0, hi, shape).astype(np.uint16 if depth == 16 else np.uint8)
+        path = str(tmp_path / ("i_%s.png" % name)); open(path, "wb").write(_adam7_png(a, depth))
+        ref = Image.open(path); assert ref.info.get("interlace") == 1
+        want = np.asarray(ref.convert("RGB")) if depth != 16 else None
+        if depth == 16:                                                   # the loader keeps the high byte of a 16-bit sample (what an 8-bit RGB request gives)
+            hi8 = (a >> 8).astype(np.uint8); want = np.repeat(hi8[..., None], 3, -1) if hi8.ndim == 2 else hi8[..., :3]
+        assert np.array_equal(decoded(path), want), name
+    a = rng.randint(0, 256, (23, 31, 3)).astype(np.uint8)
+    for name, im, kw in (("bmp24", Image.fromarray(a), {}), ("bmp8", Image.fromarray(a).quantize(100), {}), ("bmp8g", Image.fromarray(a[..., 0]), {})):
+        path = str(tmp_path / (name + ".bmp")); im.save(path, **kw)
+        assert np.array_equal(decoded(path), np.asarray(Image.open(path).convert("RGB"))), name
+    runs = np.repeat(rng.randint(0, 256, (23, 4, 3)).astype(np.uint8), 8, axis=1)[:, :31]        # long runs: the RLE packets get used
+    for name, arr, kw in (("tga", a, {}), ("tga_rle", runs, {"compression": "tga_rle"}), ("tga_grey", a[..., 0], {}), ("tga_grey_rle", runs[..., 0], {"compression": "tga_rle"}),
+                          ("tga32", np.dstack([a, a[..., :1]]), {})):
+        path = str(tmp_path / (name + ".tga")); Image.fromarray(arr).save(path, **kw)
+        assert np.array_equal(decoded(path), np.asarray(Image.open(path).convert("RGB"))), name

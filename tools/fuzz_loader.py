@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sanitizer fuzz of the host loader (OBJ / MTL / XML text, PNG and JPEG textures).
+"""Sanitizer fuzz of the host loader (OBJ / MTL / XML text; PNG incl. Adam7, baseline and progressive JPEG, BMP, TGA textures).
 
 Builds host/Model.cpp + host/Jpeg.cpp with -fsanitize=address,undefined (CPU only; the GPU pool has no
 sanitizer runs), then feeds it mutated copies of tests/golden/loader_quirks/*: truncations, byte
@@ -76,7 +76,8 @@ def run(cases, seed, workdir=None, verbose=True):
         rng = random.Random(seed)
         # (model stem, file to corrupt, is text)
         targets = [("quirk", "quirk.obj", True), ("quirk", "quirk.mtl", True), ("quirk", "quirk.xml", True),
-                   ("quirk", "tex.png", False), ("jpeg", "tex.jpg", False), ("order", "order.obj", True), ("order", "order.mtl", True)]
+                   ("quirk", "tex.png", False), ("jpeg", "tex.jpg", False), ("order", "order.obj", True), ("order", "order.mtl", True),
+                   ("formats", "tex_prog.jpg", False), ("formats", "tex_i.png", False), ("formats", "tex.bmp", False), ("formats", "tex.tga", False)]
         scene = os.path.join(workdir, "scene")
         for k in range(cases):
             stem, victim, text = targets[k % len(targets)]
