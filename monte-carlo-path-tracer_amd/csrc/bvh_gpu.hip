@@ -221,9 +221,11 @@ __global__ void ploc_merge_kernel(const Box6* __restrict__ cbox, const uint32_t*
     } else { obox[i] = cbox[i]; oref[i] = cref[i]; valid[i] = 1u; }
 }
 __global__ void ploc_compact_kernel(const Box6* __restrict__ obox, const uint32_t* __restrict__ oref, const uint32_t* __restrict__ valid,
-                                    const uint32_t* __restrict__ pos, uint32_t nc, Box6* __restrict__ cbox, uint32_t* __restrict__ cref) {
+                                    const uint32_t* __restrict__ pos, uint32_t nc, Box6* __restrict__ cbox, uint32_t* __restrict__ cref, uint32_t* __restrict__ next_nc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nc || !valid[i]) return;
+    if (i >= nc) return;
+    if (i == nc - 1) *next_nc = pos[i] + valid[i];                       // clusters left after this round: the ONE word the host reads back per round
+    if (!valid[i]) return;
     cbox[pos[i]] = obox[i]; cref[pos[i]] = oref[i];
 }
 
@@ -244,12 +246,12 @@ bool gpu_build_ploc(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string
     const float3 dlo = make_float3(lo[0], lo[1], lo[2]);
     const float3 inv = make_float3(hi[0] > lo[0] ? 1.f / (hi[0] - lo[0]) : 0.f, hi[1] > lo[1] ? 1.f / (hi[1] - lo[1]) : 0.f, hi[2] > lo[2] ? 1.f / (hi[2] - lo[2]) : 0.f);
     const uint32_t ni = n - 1;
-    DBuf d_boxes, d_k0, d_k1, d_v0, d_v1, d_left, d_right, d_nbox, d_cb0, d_cb1, d_cr0, d_cr1, d_nn, d_valid, d_pos, d_cnt, d_tmp;
+    DBuf d_boxes, d_k0, d_k1, d_v0, d_v1, d_left, d_right, d_nbox, d_cb0, d_cb1, d_cr0, d_cr1, d_nn, d_valid, d_pos, d_cnt, d_next, d_tmp;
     CK(d_boxes.alloc(sizeof(float) * 6 * (size_t)n));
     CK(d_k0.alloc(8 * (size_t)n)); CK(d_k1.alloc(8 * (size_t)n)); CK(d_v0.alloc(4 * (size_t)n)); CK(d_v1.alloc(4 * (size_t)n));
     CK(d_left.alloc(4 * (size_t)ni)); CK(d_right.alloc(4 * (size_t)ni)); CK(d_nbox.alloc(sizeof(Box6) * (size_t)ni));
     CK(d_cb0.alloc(sizeof(Box6) * (size_t)n)); CK(d_cb1.alloc(sizeof(Box6) * (size_t)n)); CK(d_cr0.alloc(4 * (size_t)n)); CK(d_cr1.alloc(4 * (size_t)n));
-    CK(d_nn.alloc(4 * (size_t)n)); CK(d_valid.alloc(4 * (size_t)n)); CK(d_pos.alloc(4 * (size_t)n)); CK(d_cnt.alloc(4));
+    CK(d_nn.alloc(4 * (size_t)n)); CK(d_valid.alloc(4 * (size_t)n)); CK(d_pos.alloc(4 * (size_t)n)); CK(d_cnt.alloc(4)); CK(d_next.alloc(4));
     CK(hipMemcpy(d_boxes.p, tri_boxes, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
     CK(hipMemset(d_cnt.p, 0, 4));
     const int B = 256;
@@ -272,11 +274,10 @@ bool gpu_build_ploc(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string
         CK(hipGetLastError());
         CK(rocprim::exclusive_scan(d_tmp.p, scan_bytes, d_valid.as<uint32_t>(), d_pos.as<uint32_t>(), 0u, (size_t)nc, rocprim::plus<uint32_t>()));
         hipLaunchKernelGGL(ploc_compact_kernel, g, dim3(B), 0, 0, d_cb1.as<Box6>(), d_cr1.as<uint32_t>(), d_valid.as<uint32_t>(), d_pos.as<uint32_t>(), nc, d_cb0.as<Box6>(),
-                           d_cr0.as<uint32_t>());
+                           d_cr0.as<uint32_t>(), d_next.as<uint32_t>());
         CK(hipGetLastError());
-        uint32_t lp = 0, lv = 0;
-        CK(hipMemcpy(&lp, d_pos.as<uint32_t>() + (nc - 1), 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&lv, d_valid.as<uint32_t>() + (nc - 1), 4, hipMemcpyDeviceToHost));
-        const uint32_t next = lp + lv;
+        uint32_t next = 0;
+        CK(hipMemcpy(&next, d_next.p, 4, hipMemcpyDeviceToHost));
         if (next >= nc) { err = "gpu_build_ploc: no pair merged (internal error)"; return false; }
         nc = next;
         if (++iterations > 4096) { err = "gpu_build_ploc: did not converge"; return false; }

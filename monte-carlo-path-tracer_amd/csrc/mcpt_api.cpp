@@ -164,8 +164,6 @@ static mcpt_status finish_ctx(mcpt_ctx* c) {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, c->device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
         c->n_cus = prop.multiProcessorCount;
-        const char* pipe = std::getenv("MCPT_PIPELINE");
-        c->use_wavefront = !(pipe && std::string(pipe) == "mega") && c->opts.integrator == MCPT_INTEGRATOR_MIS;
         c->pool_cap = 1u << std::min(26u, env_u32("MCPT_WF_POOL_LOG2", 23));
         if (c->pool_cap < 2048) c->pool_cap = 2048;
         c->items_per_slot = std::max(1u, env_u32("MCPT_WF_ITEMS_PER_SLOT", 1));
@@ -253,6 +251,9 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
 
     HostScene hs; std::string err;
     hs.bvh_width = env_u32("MCPT_BVH_WIDTH", 8) == 4 ? 4u : 8u;          // developer knob: 4 = the round-2 4-wide tree and its kernel
+    // which pipeline this context runs is decided ONCE, here: it sets how deep a device-built binary tree may be (below) and which kernels
+    // mcpt_render launches -- the two must agree, or a megakernel context could walk a tree deeper than its LDS stack
+    const bool use_wavefront = [&]() { const char* pipe = std::getenv("MCPT_PIPELINE"); return !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS; }();
     int ndev = 0;
     hipError_t e = hipSuccess;
     auto check_device = [&]() -> mcpt_status {
@@ -265,12 +266,10 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if (o.flags & MCPT_FLAG_GPU_BVH_BUILD) {                              // the tree is built on the device the context will render on
         if ((st = check_device()) != MCPT_OK) return st;
         if ((e = hipSetDevice(o.device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
-        {   // An agglomerative (PLOC) tree over millions of triangles can be deeper than the binary-tree kernels' 64-entry stack.  Only the
-            // cross-check kernels (megakernel, recursive integrator, mcpt_probe_trace) walk the binary tree; the wavefront pipeline walks
-            // the 4-wide collapse of it, whose stack is sized from its own depth -- so a wavefront-only context keeps the deep tree.
-            const char* pipe = std::getenv("MCPT_PIPELINE");
-            hs.allow_deep_binary = !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS;
-        }
+        // An agglomerative (PLOC) tree over millions of triangles can be deeper than the binary-tree kernels' 64-entry stack.  Only the
+        // cross-check kernels (megakernel, recursive integrator, mcpt_probe_trace) walk the binary tree; the wavefront pipeline walks
+        // the wide collapse of it, whose stack is sized from its own depth -- so a wavefront-only context keeps the deep tree.
+        hs.allow_deep_binary = use_wavefront;
         st = build_host_scene(scene, hs, err, [&](const float* boxes, uint32_t n, std::vector<f4h>& nodes, std::vector<int>& order, uint32_t& depth,
                                                    uint32_t& max_leaf, std::string& berr) {
             GpuBvh g;
@@ -293,7 +292,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
         return fail(MCPT_ERR_UNSUPPORTED, "scene too large for the 8-wide traversal kernel (more than 89 M triangles)");
     mcpt_ctx* c = new mcpt_ctx();
     c->device = o.device; c->opts = o; c->width = scene->camera.width; c->height = scene->camera.height;
-    c->wide_width = hs.bvh_width; c->wide_depth = hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth; c->binary_ok = hs.binary_ok;
+    c->wide_width = hs.bvh_width; c->wide_depth = hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth; c->binary_ok = hs.binary_ok; c->use_wavefront = use_wavefront;
     auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };
     if ((e = hipSetDevice(c->device)) != hipSuccess) return bail(e, "hipSetDevice");
     auto t0 = std::chrono::steady_clock::now();
@@ -339,7 +338,7 @@ mcpt_status mcpt_clone_to_device(mcpt_ctx* src, int32_t device, mcpt_ctx** out_c
     HIP_TRY(hipStreamSynchronize(src->stream));
     mcpt_ctx* c = new mcpt_ctx();
     c->device = device; c->opts = src->opts; c->opts.device = device; c->width = src->width; c->height = src->height;
-    c->wide_width = src->wide_width; c->wide_depth = src->wide_depth; c->binary_ok = src->binary_ok;
+    c->wide_width = src->wide_width; c->wide_depth = src->wide_depth; c->binary_ok = src->binary_ok; c->use_wavefront = src->use_wavefront;
     c->dev = src->dev; c->info = src->info; c->info.bvh_build_ms = 0.0;
     auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
@@ -579,6 +578,7 @@ mcpt_status mcpt_render_tiles(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
     if (tile_mod == 0 || tile_rem >= tile_mod) return fail(MCPT_ERR_INVALID_ARG, "mcpt_render_tiles: need tile_rem < tile_mod");
     if (spp == 0) return MCPT_OK;
+    if (!ctx->use_wavefront && !ctx->binary_ok) return fail(MCPT_ERR_BVH_DEPTH, "the binary tree of this (device-built) scene is deeper than the megakernel's traversal stack");
     st = resolve_timing(ctx); if (st != MCPT_OK) return st;
     RenderParams p; std::memset(&p, 0, sizeof p);
     p.spp = spp; p.first_sample = first_sample;
@@ -913,6 +913,7 @@ mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, co
         }
         return MCPT_OK;
     }
+    if (!ctx->binary_ok) return fail(MCPT_ERR_BVH_DEPTH, "the binary tree of this (device-built) scene is deeper than the megakernel's traversal stack");
     HIP_TRY(launch_probe_paths(ctx->dev, p, n, d_o, d_d, d_out, d_cnt, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(out_L3, d_out, 3 * size_t(n) * sizeof(float), hipMemcpyDeviceToHost));

@@ -221,7 +221,23 @@ Color3f Texture::get_color(const dvec2& uv) const {
 // overflow ...), and the chunks are stitched together in file order.  `mtllib` and `usemtl` lines are order-dependent (a usemtl
 // resolves against the file's materials, model.cpp:131-136): chunks only record them, the stitching replays them in order.
 namespace {
-struct ObjEvent { bool is_mtllib; std::string text; };          // mtllib: the rest of the line; usemtl: the rest of the line
+// regex_search(line, "<keyword>\\s+(\\S+)") of model.cpp:67 / :134 without <regex>: the leftmost place where the keyword is followed by at least
+// one white-space character and then a non-empty run of non-white-space characters; returns that run, or false.  ("usemtl" alone, or
+// "usemtlwood", matches nothing and leaves the current material as it is; "u usemtl wood" does switch.)
+bool keyword_arg(const std::string& line, const char* kw, std::string& arg) {
+    auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; };
+    const size_t kn = std::strlen(kw);
+    for (size_t at = line.find(kw); at != std::string::npos; at = line.find(kw, at + 1)) {
+        size_t q = at + kn;
+        if (q >= line.size() || !is_space(line[q])) continue;
+        while (q < line.size() && is_space(line[q])) q++;
+        size_t e = q;
+        while (e < line.size() && !is_space(line[e])) e++;
+        if (e > q) { arg = line.substr(q, e - q); return true; }
+    }
+    return false;
+}
+struct ObjEvent { bool is_mtllib; std::string text; };          // the whole line (it starts with 'm' or with 'u')
 struct ObjChunk {
     std::vector<dvec3> vertex, normal;
     std::vector<dvec2> texture;
@@ -277,7 +293,7 @@ void parse_obj_chunk(const char* b, const char* e, bool reference_index_order, O
         if (le > p && le[-1] == '\r') le--;
         const size_t n = size_t(le - p);
         auto begins = [&](const char* t, size_t tn) { return n >= tn && std::memcmp(p, t, tn) == 0; };
-        if (begins("mtllib", 6)) out.events.push_back({true, std::string(p + 6, le)});
+        if (n && p[0] == 'm') out.events.push_back({true, std::string(p, le)});          // model.cpp:64: any line that starts with 'm'; the name is searched for later
         else if (begins("v ", 2)) {
             dvec3 v; const char* q = p + 2;
             if (slow_only || !(fast_double(q, le, v.x) && fast_double(q, le, v.y) && fast_double(q, le, v.z))) { v = dvec3(); slow_vec(std::string(p, le), 2, 3, &v.x); }
@@ -290,7 +306,7 @@ void parse_obj_chunk(const char* b, const char* e, bool reference_index_order, O
             dvec2 v; const char* q = p + std::min<size_t>(3, n);
             if (slow_only || !(fast_double(q, le, v.x) && fast_double(q, le, v.y))) { v = dvec2(); slow_vec(std::string(p, le), 3, 2, &v.x); }
             out.texture.push_back(v);
-        } else if (begins("usemtl", 6)) { out.last_usemtl = int(out.events.size()); out.events.push_back({false, std::string(p + 6, le)}); }
+        } else if (n && p[0] == 'u') { out.last_usemtl = int(out.events.size()); out.events.push_back({false, std::string(p, le)}); }   // model.cpp:88: any line that starts with 'u'
         else if (begins("f ", 2)) {
             imat3x4 f; const char* q = p + 2; bool fast = !slow_only;
             for (int i = 0; i < 3 && fast; i++) {
@@ -345,8 +361,8 @@ Model::Model(const std::string& filename, bool reference_index_order) {
     // of ANY mtllib line of the file, also a later one; an unknown name is material 0 (`material_map[name]` default-inserts 0)
     for (const ObjChunk& c : chunks)
         for (const ObjEvent& ev : c.events) {
-            if (!ev.is_mtllib) continue;
-            std::istringstream ss(ev.text); std::string name; ss >> name;
+            std::string name;
+            if (!ev.is_mtllib || !keyword_arg(ev.text, "mtllib", name)) continue;
             if (name.size() > 3) {
                 std::string xml = name; xml.replace(xml.size() - 3, 3, "xml");
                 loadCameraFromXML(parent + "/" + xml);              // camera first: radiance is attached while materials load (model.cpp:71-72)
@@ -359,9 +375,11 @@ Model::Model(const std::string& filename, bool reference_index_order) {
         const int carried = cur_mtl;
         for (size_t i = 0; i < c.events.size(); i++) {
             if (c.events[i].is_mtllib) continue;
-            std::istringstream ss(c.events[i].text); std::string name; ss >> name;
-            auto it = material_map.find(name);
-            cur_mtl = it == material_map.end() ? 0 : it->second;
+            std::string name;
+            if (keyword_arg(c.events[i].text, "usemtl", name)) {            // no match: the material in force stays (model.cpp:134)
+                auto it = material_map.find(name);
+                cur_mtl = it == material_map.end() ? 0 : it->second;
+            }
             resolved[i] = cur_mtl;
         }
         vertex.insert(vertex.end(), c.vertex.begin(), c.vertex.end());

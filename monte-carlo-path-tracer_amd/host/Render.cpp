@@ -66,6 +66,7 @@ void Render::flush_into(Scene& scene) {
     if (mcpt_read_accum(ctx, film.data()) != MCPT_OK || mcpt_clear_accum(ctx) != MCPT_OK) { std::cerr << "Error: film read-back: " << mcpt_last_error() << std::endl; return; }
     scene.add_film(film.data());
 }
+void Render::displaced(Scene& scene) { if (&scene == target) target = nullptr; }   // (already flushed by Scene::attach)
 void Render::scene_gone(Scene& scene) {
     if (&scene != target) return;
     target = nullptr;

@@ -18,6 +18,7 @@ public:
     // Scene::sync -- or rendered into by another Render, or either object goes away.
     void flush_into(Scene& scene) override;
     void scene_gone(Scene& scene) override;
+    void displaced(Scene& scene) override;
     Render(const Render&) = delete;
     Render& operator=(const Render&) = delete;
     bool ok() const { return ctx != nullptr; }

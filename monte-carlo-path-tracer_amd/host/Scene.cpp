@@ -28,6 +28,7 @@ Scene::~Scene() { if (m_source) m_source->scene_gone(*this); }
 void Scene::attach(FilmSource* source) {
     if (m_source == source) return;
     sync();
+    if (m_source) m_source->displaced(*this);         // (two Renders sharing one Scene: the first must not call detach() on a Scene that died meanwhile)
     m_source = source;
 }
 void Scene::detach(FilmSource* source) { if (m_source == source) m_source = nullptr; }

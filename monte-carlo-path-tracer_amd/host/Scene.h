@@ -16,6 +16,8 @@ public:
     virtual ~FilmSource() {}
     virtual void flush_into(class Scene& scene) = 0;     // add the held samples to `scene` (Scene::add_film) and forget them
     virtual void scene_gone(class Scene& scene) = 0;     // `scene` is being destroyed: drop what was held for it
+    virtual void displaced(class Scene& scene) = 0;      // another source took `scene` over (this one was flushed first): forget the scene --
+                                                         // it may be destroyed without this source ever hearing of it again
 };
 
 class Scene {

@@ -72,9 +72,12 @@ def test_quirk_file_parses_like_the_reference(tmp_path):
     ref = _golden("quirk_")
     mine = _dump(QUIRK, tmp_path)
     _compare(mine, ref, "quirk")
-    # the quirks really are in the golden: 5 faces from 5 `f` lines (one with four corners), the blank-led vertex line ignored,
+    # the quirks really are in the golden: 9 faces from 9 `f` lines (one with four corners), the blank-led vertex line ignored,
     # the Ks line with a '#' dropped (Ks stays 0), unknown usemtl -> material 0, light radiance attached by name
-    assert ref["vertex"].shape == (5, 3) and ref["face"].shape == (5, 3, 4)
+    assert ref["vertex"].shape == (5, 3) and ref["face"].shape == (9, 3, 4)
+    # malformed usemtl lines (model.cpp:134 regex_search "usemtl\\s+(\\S+)"): a bare `usemtl` and `usemtlred` match nothing and keep the
+    # material in force (lamp = 3); `u usemtl red` does switch (0); only the first word after the keyword counts (textured = 1)
+    assert [int(x) for x in ref["face"][4:, 0, 3]] == [3, 3, 3, 0, 1]
     assert np.array_equal(ref["face"][1, :, :3], [[0, 1, 2], [2, 0, 1], [3, 2, 0]])          # a/b/c with b != c
     assert not ref["materials"][0, :3].any() and ref["materials"][0, 6] == 25
     assert np.array_equal(ref["face"][3, :, 3], [0, 0, 0]) and np.array_equal(ref["materials"][3, 8:11], [10, 8.5, 6])
