@@ -219,26 +219,41 @@ struct CollapsePlan {
     std::vector<unsigned char> split;                                   // [n * (K + 1) + i]
     unsigned char at(int n, int i) const { return split[size_t(n) * (K + 1) + i]; }
 };
-CollapsePlan plan_collapse(const std::vector<f4h>& n2, int K) {
+CollapsePlan plan_collapse(const std::vector<f4h>& n2, int K, const std::vector<int>& subtree_begin = std::vector<int>()) {
     const int N = int(n2.size() / 4);
     CollapsePlan p; p.K = K; p.split.assign(size_t(N) * (K + 1), 0);
-    std::vector<int> order; order.reserve(N);                           // parents before children
-    { std::vector<int> st{0}; while (!st.empty()) { const int n = st.back(); st.pop_back(); order.push_back(n); for (int k = 0; k < 2; k++) { const int c = child2(n2, n, k); if (c >= 0) st.push_back(c); } } }
     auto own_area = [&](int n) { Box3f a = box2(n2, n, 0); const Box3f b = box2(n2, n, 1); for (int x = 0; x < 3; x++) { a.lo[x] = std::min(a.lo[x], b.lo[x]); a.hi[x] = std::max(a.hi[x], b.hi[x]); } return area3(a); };
     const double root_area = std::max(own_area(0), 1e-300);
     std::vector<double> cost(size_t(N) * (K + 1), 0.0);
     auto C = [&](int code, int i) { return code < 0 ? 0.0 : cost[size_t(code) * (K + 1) + i]; };   // a leaf is no node visit, in any number of slots
-    for (int idx = N - 1; idx >= 0; idx--) {
-        const int n = order[size_t(idx)], l = child2(n2, n, 0), r = child2(n2, n, 1);
-        auto distribute = [&](int j, int& best_a) { double best = 1e300; for (int a = 1; a < j; a++) { const double c = C(l, a) + C(r, j - a); if (c < best) { best = c; best_a = a; } } return best; };
-        int a = 1;
-        cost[size_t(n) * (K + 1) + 1] = own_area(n) / root_area + distribute(K, a); p.split[size_t(n) * (K + 1) + 1] = (unsigned char)a;
-        for (int i = 2; i <= K; i++) {
-            const double d = distribute(i, a), keep = cost[size_t(n) * (K + 1) + i - 1];
-            if (d < keep) { cost[size_t(n) * (K + 1) + i] = d; p.split[size_t(n) * (K + 1) + i] = (unsigned char)a; }
-            else { cost[size_t(n) * (K + 1) + i] = keep; p.split[size_t(n) * (K + 1) + i] = 0; }
+    // The builder's renumbering puts every parent before its children, so descending index order is children first; below the top levels
+    // every subtree is one contiguous index range (subtree_begin), and disjoint subtrees do not read each other's costs.
+    auto range = [&](int lo, int hi) {
+        for (int n = hi - 1; n >= lo; n--) {
+            const int l = child2(n2, n, 0), r = child2(n2, n, 1);
+            auto distribute = [&](int j, int& best_a) { double best = 1e300; for (int a = 1; a < j; a++) { const double c = C(l, a) + C(r, j - a); if (c < best) { best = c; best_a = a; } } return best; };
+            int a = 1;
+            cost[size_t(n) * (K + 1) + 1] = own_area(n) / root_area + distribute(K, a); p.split[size_t(n) * (K + 1) + 1] = (unsigned char)a;
+            for (int i = 2; i <= K; i++) {
+                const double d = distribute(i, a), keep = cost[size_t(n) * (K + 1) + i - 1];
+                if (d < keep) { cost[size_t(n) * (K + 1) + i] = d; p.split[size_t(n) * (K + 1) + i] = (unsigned char)a; }
+                else { cost[size_t(n) * (K + 1) + i] = keep; p.split[size_t(n) * (K + 1) + i] = 0; }
+            }
         }
+    };
+    int top = N;
+    if (subtree_begin.size() > 1 && N >= (1 << 16)) {
+        top = subtree_begin[0];
+        const uint32_t ns = uint32_t(subtree_begin.size());
+        std::atomic<uint32_t> next{0};
+        auto worker = [&]() { for (uint32_t k = next.fetch_add(1); k < ns; k = next.fetch_add(1)) range(subtree_begin[k], k + 1 < ns ? subtree_begin[k + 1] : N); };
+        const uint32_t nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (uint32_t t = 1; t < nt; t++) { try { th.emplace_back(worker); } catch (const std::system_error&) { break; } }
+        worker();
+        for (auto& t : th) t.join();
     }
+    range(0, top);
     return p;
 }
 // The children a K-wide node adopts under the plan: the roots of the forest below binary node `node2` that fills its K slots.
@@ -348,17 +363,27 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
     static_assert(MCPT_LEAF_MAX <= 3, "a leaf child's triangle count is two bits in the 8-wide node");
     std::vector<f4h>& n2 = out.nodes;
     std::vector<f4h>& n8 = out.nodes8;
-    const CollapsePlan plan = plan_collapse(n2, 8);
-    struct Work { int node2, rec; uint32_t depth; };
-    std::vector<Work> queue{{0, 0, 1}};
+    const auto tb0 = std::chrono::steady_clock::now();
+    const CollapsePlan plan = plan_collapse(n2, 8, out.subtree_begin);
+    if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build]   collapse plan (dynamic programme) %.0f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
+    // Breadth-first, one level at a time: the nodes of a level are independent (children gathered from the plan, octant slots, quantised
+    // planes: all threads), then one serial sweep over the level hands out the children's record numbers and the leaf triangles' positions
+    // in node order -- so the numbering is the serial one, whatever the thread count.
+    struct Work { int node2, rec; };
+    struct Emit { int inner2[8]; uint32_t leaf_first[8]; unsigned char leaf_cnt[8]; unsigned char n_inner, n_leaf; };
+    std::vector<Work> level{{0, 0}}, next_level;
+    std::vector<Emit> emit;
     n8.assign(5, f4h{0.f, 0.f, 0.f, 0.f});
-    out.bvh8_depth = 1;
+    out.bvh8_depth = 0;
     std::vector<int> new_order; new_order.reserve(order.size());
     std::vector<int> new_first(order.size() + 1, -1);                   // old first position of a leaf -> its new one
-    std::vector<Kid> kids;
-    for (size_t qh = 0; qh < queue.size(); qh++) {
-        const Work w = queue[qh];
-        out.bvh8_depth = std::max(out.bvh8_depth, w.depth);
+    while (!level.empty()) {
+        out.bvh8_depth++;
+        emit.assign(level.size(), Emit());
+        parallel_for(uint32_t(level.size()), [&](uint32_t i_begin, uint32_t i_end) {
+        std::vector<Kid> kids;
+        for (uint32_t wi = i_begin; wi < i_end; wi++) {
+        const Work w = level[wi];
         kids.clear();
         planned_kids(n2, plan, w.node2, kids);
         for (size_t i = 0; i < kids.size();) { if (kids[i].code < 0 && ((uint32_t(~kids[i].code)) & 7u) == 0) kids.erase(kids.begin() + i); else i++; }   // (the empty second child of a one-leaf scene)
@@ -368,18 +393,18 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
         for (const Kid& k : kids) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], k.box.lo[a]); hi[a] = std::max(hi[a], k.box.hi[a]); }
         if (kids.empty()) { for (int a = 0; a < 3; a++) lo[a] = hi[a] = 0.f; }
         // octant slots: greedily give the (child, slot) pair with the largest projection of the child's offset from the node centre on the slot's diagonal
-        int slot_of[8]; int kid_in[8]; for (int sl = 0; sl < 8; sl++) kid_in[sl] = -1;
+        int kid_in[8]; for (int sl = 0; sl < 8; sl++) kid_in[sl] = -1;
         {
             double cost[8][8]; bool ck[8] = {false}, cs[8] = {false};
-            for (int k = 0; k < nk; k++) for (int sl = 0; sl < 8; sl++) {
-                double v = 0;
-                for (int a = 0; a < 3; a++) { const double cc = 0.5 * (double(kids[k].box.lo[a]) + kids[k].box.hi[a]) - 0.5 * (double(lo[a]) + hi[a]); v += ((sl >> a) & 1) ? cc : -cc; }
-                cost[k][sl] = v;
+            for (int k = 0; k < nk; k++) {
+                double cc[3];
+                for (int a = 0; a < 3; a++) cc[a] = 0.5 * (double(kids[k].box.lo[a]) + kids[k].box.hi[a]) - 0.5 * (double(lo[a]) + hi[a]);
+                for (int sl = 0; sl < 8; sl++) { double v = 0; for (int a = 0; a < 3; a++) v += ((sl >> a) & 1) ? cc[a] : -cc[a]; cost[k][sl] = v; }
             }
             for (int r = 0; r < nk; r++) {
                 int bk = -1, bs = -1; double bv = -INFINITY;
                 for (int k = 0; k < nk; k++) if (!ck[k]) for (int sl = 0; sl < 8; sl++) if (!cs[sl] && (bk < 0 || cost[k][sl] > bv)) { bv = cost[k][sl]; bk = k; bs = sl; }
-                ck[bk] = cs[bs] = true; slot_of[bk] = bs; kid_in[bs] = bk;
+                ck[bk] = cs[bs] = true; kid_in[bs] = bk;
             }
         }
         int ebits[3]; double scale[3];
@@ -394,7 +419,7 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
         uint32_t q[3][2][2];                                                         // [axis][lo / hi][slots 0-3 / 4-7]
         for (int a = 0; a < 3; a++) { q[a][0][0] = q[a][0][1] = 0xffffffffu; q[a][1][0] = q[a][1][1] = 0u; }
         uint32_t imask = 0, p0 = 0, p1 = 0;
-        const uint32_t child_base = uint32_t(n8.size() / 5), tri_base = uint32_t(new_order.size());
+        Emit& em = emit[wi];
         for (int sl = 0; sl < 8; sl++) {
             const int k = kid_in[sl]; if (k < 0) continue;
             for (int a = 0; a < 3; a++) {
@@ -407,24 +432,36 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
                 q[a][0][h] = (q[a][0][h] & ~(0xffu << sh)) | (uint32_t(ql) << sh);
                 q[a][1][h] = (q[a][1][h] & ~(0xffu << sh)) | (uint32_t(qh) << sh);
             }
-            if (kids[k].code >= 0) {                                                 // inner child: its record follows its lower-slot siblings
-                imask |= 1u << sl;
-                const int rec = int(n8.size() / 5);
-                n8.resize(n8.size() + 5, f4h{0.f, 0.f, 0.f, 0.f});
-                queue.push_back({kids[k].code, rec, w.depth + 1});
-            } else {                                                                 // leaf child: its triangles follow those of its lower-slot siblings
-                const uint32_t leaf = uint32_t(~kids[k].code), first = leaf >> 3, cnt = leaf & 7u;
+            if (kids[k].code >= 0) { imask |= 1u << sl; em.inner2[em.n_inner++] = kids[k].code; }        // inner children: records in slot order
+            else {                                                                   // leaf children: triangles in slot order
+                const uint32_t leaf = uint32_t(~kids[k].code), cnt = leaf & 7u;
                 p0 |= (cnt & 1u) << sl; p1 |= ((cnt >> 1) & 1u) << sl;
-                new_first[first] = int(new_order.size());
-                for (uint32_t i = 0; i < cnt; i++) new_order.push_back(order[first + i]);
+                em.leaf_first[em.n_leaf] = leaf >> 3; em.leaf_cnt[em.n_leaf++] = (unsigned char)cnt;
             }
         }
         f4h* r = &n8[5 * size_t(w.rec)];
         r[0] = {lo[0], lo[1], lo[2], from_u32((bf16_pow2(ebits[0]) << 16) | bf16_pow2(ebits[1]))};
-        r[1] = {from_u32(child_base), from_u32(tri_base), from_u32(bf16_pow2(ebits[2]) << 16), from_u32(imask | (p0 << 8) | (p1 << 16) | ((p0 | p1) << 24))};
+        r[1] = {0.f, 0.f, from_u32(bf16_pow2(ebits[2]) << 16), from_u32(imask | (p0 << 8) | (p1 << 16) | ((p0 | p1) << 24))};   // child_base / tri_base: the sweep below
         r[2] = {from_u32(q[0][0][0]), from_u32(q[0][0][1]), from_u32(q[0][1][0]), from_u32(q[0][1][1])};   // x: lo 0-3, lo 4-7, hi 0-3, hi 4-7
         r[3] = {from_u32(q[1][0][0]), from_u32(q[1][0][1]), from_u32(q[1][1][0]), from_u32(q[1][1][1])};   // y
         r[4] = {from_u32(q[2][0][0]), from_u32(q[2][0][1]), from_u32(q[2][1][0]), from_u32(q[2][1][1])};   // z
+        }
+        });
+        // the serial sweep: record numbers of the next level, triangle positions
+        next_level.clear();
+        size_t n_rec = n8.size() / 5;
+        for (size_t wi = 0; wi < level.size(); wi++) {
+            const Emit& em = emit[wi];
+            f4h* r = &n8[5 * size_t(level[wi].rec)];          // (n8 grows only after this loop)
+            r[1].x = from_u32(uint32_t(n_rec)); r[1].y = from_u32(uint32_t(new_order.size()));
+            for (int i = 0; i < em.n_inner; i++) next_level.push_back({em.inner2[i], int(n_rec++)});
+            for (int i = 0; i < em.n_leaf; i++) {
+                new_first[em.leaf_first[i]] = int(new_order.size());
+                for (uint32_t t = 0; t < em.leaf_cnt[i]; t++) new_order.push_back(order[em.leaf_first[i] + t]);
+            }
+        }
+        n8.resize(5 * n_rec, f4h{0.f, 0.f, 0.f, 0.f});
+        level.swap(next_level);
     }
     // the new leaf order: every triangle stream and the binary tree's leaf codes follow it
     const size_t nb = n2.size() / 4;
@@ -645,8 +682,11 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         }
         std::vector<int> stack;
         for (size_t i = queue.size(); i-- > qh;) stack.push_back(queue[i]);           // remaining frontier, in BFS order
+        const size_t frontier_left = stack.size();
+        out.subtree_begin.clear();
         while (!stack.empty()) {
             const int n = stack.back(); stack.pop_back();
+            if (stack.size() < frontier_left - out.subtree_begin.size()) out.subtree_begin.push_back(int(order_new.size()));   // a frontier node: its whole subtree follows, contiguously
             new_id[n] = int(order_new.size()); order_new.push_back(n);
             const int c0 = child(n, 0), c1 = child(n, 1);
             if (c1 >= 0) stack.push_back(c1);

@@ -26,6 +26,7 @@ struct HostScene {
     DevCamera cam;
     double centre[3] = {0.0, 0.0, 0.0};   // the point every coordinate above is relative to (device_scene.h: DevScene::centre)
     uint32_t bvh_depth = 0, max_leaf = 0, bvh4_depth = 0, bvh8_depth = 0;
+    std::vector<int> subtree_begin;  // binary nodes: first index of every depth-first-numbered subtree below the breadth-first top levels (ascending)
     uint32_t bvh_width = 8;          // in: which wide tree the wavefront trace kernel will walk (4 = the round-2 tree, a developer knob)
     bool allow_deep_binary = false;  // in: the caller never traverses `nodes` (wavefront pipeline only) -> a device tree deeper than MCPT_STACK_DEPTH is fine
     bool binary_ok = true;           // out: `nodes` fits the binary-tree kernels' stack
