@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     // later launch of the job ends here, before it streams the pool.  (An empty iteration used to cost 0.5 - 0.65 ms in this kernel and
     // 0.2 - 0.4 ms in the trace kernel: ~10 % of a 128-spp share of a strong-scaled job.)
     if (it != 0u && ctl->any_active[(it - 1u) & 3u] == 0u) return;
-    __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64], s_shadow_cnt[WF_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base, s_sel, s_scan, s_priv_base, s_priv_take, s_priv_next, s_priv_end;
     // the whole slot state of the block's 256-slot window, fetched coalesced in ONE batch by the slots' own lanes and handed to the
     // lanes that will process them through LDS: no dependent second round of (gathering) global loads after the sort ...
@@ -174,9 +174,13 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
             if (lane == k) s_kcnt[k * (WF_SHADE_BLOCK / 64) + wv] = (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < K_COUNT * (WF_SHADE_BLOCK / 64); i++) { const uint32_t c = s_kcnt[i]; s_kcnt[i] = run; run += c; } }
-        __syncthreads();
-        s_perm[s_kcnt[skey * (WF_SHADE_BLOCK / 64) + wv] + my_rank] = tid | (key << 16);
+        // exclusive prefix of the slot's (key, wave) counter over the [key][wave] table, summed by every thread for itself (20 broadcast LDS
+        // reads) -- a serial scan by one thread between two barriers cost a barrier
+        uint32_t before_me = 0;
+        const uint32_t my_cell = skey * (WF_SHADE_BLOCK / 64) + wv;
+#pragma unroll
+        for (uint32_t i = 0; i < K_COUNT * (WF_SHADE_BLOCK / 64); i++) before_me += i < my_cell ? s_kcnt[i] : 0u;
+        s_perm[before_me + my_rank] = tid | (key << 16);
         __syncthreads();
     }
 #ifdef MCPT_SHADE_PERM_TEST     // diagnostic: a class-blind interleave -- every wave touches every line of the window, no sorting benefit
@@ -406,7 +410,6 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
                 }
             }
         }
-        __syncthreads();                                                                        // s_wave_cnt / s_base are reused below
     }
     if (state == SLOT_DEAD && id.z < id.w) {                                                    // next sample of the item: camera ray
         id.y = id.z++; id_dirty = true;
@@ -444,12 +447,12 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     //      block's four waves at the barrier for its round trip: 0.58 vs 0.24 ms per launch.)
     const uint32_t cur = it & 3;
     const uint64_t ms = __ballot(emit_shadow);
-    if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(ms);
+    if (lane == 0) s_shadow_cnt[wv] = (uint32_t)__popcll(ms);                                   // (cells of their own: the item pull's s_wave_cnt may still be read by slower waves)
     __syncthreads();
-    if (tid == 0) { uint32_t tot = 0; for (uint32_t k = 0; k < WF_SHADE_BLOCK / 64; k++) tot += s_wave_cnt[k]; st_s(&pool.shadow_count[blockIdx.x], tot); }
+    if (tid == 0) { uint32_t tot = 0; for (uint32_t k = 0; k < WF_SHADE_BLOCK / 64; k++) tot += s_shadow_cnt[k]; st_s(&pool.shadow_count[blockIdx.x], tot); }
     if (emit_shadow) {
         uint32_t before = 0;
-        for (uint32_t k = 0; k < wv; k++) before += s_wave_cnt[k];
+        for (uint32_t k = 0; k < wv; k++) before += s_shadow_cnt[k];
         // the shadow ray goes to the queue as a complete record (origin | triangle to skip, direction | t2, slot): the trace kernel reads a
         // queued ray in ONE coalesced round trip instead of chasing queue -> slot -> ray records through two
         const uint32_t q = base + before + lane_rank(ms);

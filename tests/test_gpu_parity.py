@@ -1179,3 +1179,22 @@ def test_clone_to_device_shares_nothing_but_the_scene(pkg):
     a.close()
     b.render(8, seed=9, first_sample=8); assert np.all(b.read_accum()[..., 3] == 16)       # the clone outlives its source
     b.close()
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """`bench.py --gpus 2` on the nccl (= RCCL) backend: its own launcher starts two ranks, each renders its sample range on its own GPU and the
+    fp32 films are summed by one all-reduce inside the timed region -- the path the driver's SCALE run takes.  Skipped on a one-GPU box (the
+    gloo rehearsal of the same code path runs on CPU: tests/test_bench_launcher.py); a rank that dies takes the launch down (bounded)."""
+    import json, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2: pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MCPT_BENCH_LAUNCH_TIMEOUT"] = "600"
+    for shard in ("samples", "tiles"):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "64", "--no-cpu-baseline", "--shard", shard],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["film_count_plane_ok"] is True
+        assert out["scaling"] == ("strong" if shard == "tiles" else "weak") and out["value"] > 0
