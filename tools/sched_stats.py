@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Developer tool: scheduler statistics of the trace kernel (needs a library built with -DWF_SCHED_STATS; counters are re-purposed).
-usage: MCPT_LIB_PATH=build/libmcpt_hip_stats.so python tools/sched_stats.py [spp]"""
+usage: MCPT_LIB_PATH=build/libmcpt_hip_stats.so python tools/sched_stats.py [spp] [c2|c3|c4|c5]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 os.environ["MCPT_TIME_KERNELS"] = "1"
-r = pkg.Renderer(pkg.scenes.cornell_box(800, 800), max_depth=8, flags=4)
+cfg_name = sys.argv[2] if len(sys.argv) > 2 else "c2"                   # a BASELINE.json configuration of bench.py
+import bench
+cfg = bench.CONFIGS[cfg_name]
+r = pkg.Renderer(pkg.scenes.SCENES[cfg["scene"]](cfg["res"][0], cfg["res"][1], **cfg["kw"]), max_depth=cfg["depth"], flags=4)
 r.render(spp, seed=1); r.sync(); c = r.counters()
 rays = c.rays
-print("rays %.3g  inner: execs/ray %.4f lanes/exec %.1f (steps/ray %.2f) | leaf: execs/ray %.4f lanes/exec %.1f (visits/ray %.2f) | refill execs/ray %.4f free slots/exec %.1f" % (
+print(cfg_name, "rays %.3g  inner: execs/ray %.4f lanes/exec %.1f (steps/ray %.2f) | leaf: execs/ray %.4f lanes/exec %.1f (visits/ray %.2f) | refill execs/ray %.4f free slots/exec %.1f" % (
     rays, c.shaded_hits / rays, c.box_tests / max(1, c.shaded_hits), c.box_tests / rays, c.texel_fetches / rays, c.tri_tests / max(1, c.texel_fetches),
     c.tri_tests / rays, c.self_shadow_tests / rays, c.self_shadow_hits / max(1, c.self_shadow_tests)), flush=True)
 i = r.info()
-grid = int(os.environ.get("MCPT_WF_GRID", "192"))
+grid = int(os.environ.get("MCPT_WF_GRID", "256"))
 waves = grid * 16
 print("trace launches %d, mean launch %.3f ms; mean wave lifetime %.3f ms = %.1f %% of the launch (grid %d blocks assumed)" % (
     c.iterations, c.trace_ms_total / c.iterations, c.paths * 1e-5 / (c.iterations * waves), 100.0 * c.paths * 1e-5 / (waves * c.trace_ms_total), grid), flush=True)
