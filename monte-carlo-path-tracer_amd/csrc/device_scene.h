@@ -24,7 +24,9 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
+#ifndef MCPT_LEAF_MAX
 #define MCPT_LEAF_MAX 2
+#endif
 #ifndef MCPT_STACK_DEPTH
 #define MCPT_STACK_DEPTH 64        // LDS traversal stack entries per lane of the binary-tree kernels (host SAH trees: depth <= 30; device LBVH trees: <= 63, checked)
 #endif
