@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ v2u s_stack[WF8_LDS_STACK * WF_TRACE_BLOCK];
-    __shared__ float4 s_top[5 * MCPT_TOP_NODES8];                      // [record][node]
+    __shared__ float4 s_top[5 * MCPT_TOP_NODES8 + 1];                  // [record][node]  (+1: MCPT_TOP_NODES8 = 0 is a legal A/B setting)
     typedef __attribute__((address_space(3))) v2u lds_u2;              // explicit address spaces: see wf_trace_kernel
     typedef __attribute__((address_space(3))) v4f lds_f4;
     typedef __attribute__((address_space(1))) v2u glb_u2;
