@@ -124,6 +124,8 @@ typedef struct mcpt_scene_info {
     uint32_t wide_width, wide_nodes, wide_depth, reserved0;
     uint64_t traversal_bytes;   /* wide nodes + triangle intersection records: what a ray's traversal can touch */
     double   centre[3];         /* device coordinates are relative to this point (the fp64 centre of the scene's bounding box) */
+    uint64_t wide_tree_hash;    /* FNV-1a over the wide tree's records and the leaf order: equal hashes = the same tree and triangle order
+                                   (how the tests tell that the device collapse reproduces the host collapse bit for bit) */
 } mcpt_scene_info;
 
 typedef struct mcpt_ctx mcpt_ctx;

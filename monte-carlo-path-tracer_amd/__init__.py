@@ -82,7 +82,7 @@ class SceneInfo(C.Structure):
                 ("bvh_depth", C.c_uint32), ("max_leaf", C.c_uint32), ("width", C.c_uint32),
                 ("height", C.c_uint32), ("device_bytes", C.c_uint64), ("bvh_build_ms", C.c_double),
                 ("upload_ms", C.c_double), ("wide_width", C.c_uint32), ("wide_nodes", C.c_uint32), ("wide_depth", C.c_uint32),
-                ("reserved0", C.c_uint32), ("traversal_bytes", C.c_uint64), ("centre", C.c_double * 3)]
+                ("reserved0", C.c_uint32), ("traversal_bytes", C.c_uint64), ("centre", C.c_double * 3), ("wide_tree_hash", C.c_uint64)]
 
 
 def texture_to_float(img_u8: np.ndarray) -> np.ndarray:

@@ -510,3 +510,251 @@ bool gpu_collapse_bvh4(const std::vector<f4h>& nodes2, std::vector<f4h>& nodes4,
     CK(hipMemcpy(nodes4.data(), d_n4.p, 64 * (size_t)n4, hipMemcpyDeviceToHost));
     return true;
 }
+
+
+// ---------------------------------------------------------------------------------------------- 8-wide collapse (round 3)
+// The device version of build_bvh8 (scene_build.cpp), statement for statement: the same dynamic programme (double arithmetic, contraction
+// off, so that the plan -- and with it every record and the leaf order -- is the host's bit for bit; tests/test_gpu_bvh_build.py compares the
+// two), the same breadth-first emission one level at a time.
+//   1. parent_kernel     every inner child learns its parent; a node's arrival counter starts at its number of leaf children
+//   2. plan_kernel       bottom-up: a thread starts at every node whose children are both leaves and climbs; the SECOND arrival at a node
+//                        (atomic counter) computes it -- cost[n][1..8] and split[n][1..8] of plan_collapse
+//   3. per level:        emit_kernel (children from the plan, octant slots, quantised planes -> the record without its two bases + the
+//                        inner / leaf children in slot order), two exclusive scans (inner children, leaf triangles), number_kernel (child
+//                        base, triangle base, the next level's work list, the triangles' new positions) -- the serial sweep of the host code
+//   4. remap_kernel      the binary tree's leaf codes follow the new leaf order
+namespace {
+struct C8Item { int node2, rec; };
+struct C8Emit { int inner2[8]; uint32_t leaf_first[8]; unsigned char leaf_cnt[8]; uint32_t n_inner, n_leaf, leaf_tris; };
+constexpr int K8 = 8;
+
+__device__ __forceinline__ int c8_child(const float4* __restrict__ n2, int n, int k) { const float4 c = n2[4 * (size_t)n + 3]; return __float_as_int(k == 0 ? c.x : c.y); }
+__device__ __forceinline__ double c8_area(const float* lo, const float* hi) {
+#pragma clang fp contract(off)
+    const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+    return 2.0 * (x * y + y * z + z * x);
+}
+__device__ __forceinline__ double c8_own_area(const float4* __restrict__ n2, int n) {
+    const KidD a = kid_of(n2, n, 0), b = kid_of(n2, n, 1);
+    float lo[3], hi[3];
+    for (int x = 0; x < 3; x++) { lo[x] = fminf(a.lo[x], b.lo[x]); hi[x] = fmaxf(a.hi[x], b.hi[x]); }
+    return c8_area(lo, hi);
+}
+
+__global__ void c8_parent_kernel(const float4* __restrict__ n2, uint32_t n, int* __restrict__ parent, uint32_t* __restrict__ arrive) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t leaves = 0;
+    for (int k = 0; k < 2; k++) { const int c = c8_child(n2, (int)i, k); if (c >= 0) parent[c] = (int)i; else leaves++; }
+    arrive[i] = leaves;
+    if (i == 0) parent[0] = -1;
+}
+
+__device__ void c8_plan_node(const float4* __restrict__ n2, int n, double inv_root_area_unused, double root_area, double* __restrict__ cost, unsigned char* __restrict__ split) {
+#pragma clang fp contract(off)
+    const int l = c8_child(n2, n, 0), r = c8_child(n2, n, 1);
+    double cl[K8 + 1], cr[K8 + 1];
+    // a child's costs were written by another thread, possibly on another CU: agent-scope loads (the per-CU vector L1 is not refreshed by other
+    // CUs' stores, and a 128-B line holds more than one node's costs), paired with the fences around the arrival counter in c8_plan_kernel
+    auto ld = [](const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (int i = 1; i <= K8; i++) { cl[i] = l < 0 ? 0.0 : ld(&cost[(size_t)l * (K8 + 1) + i]); cr[i] = r < 0 ? 0.0 : ld(&cost[(size_t)r * (K8 + 1) + i]); }
+    double* cn = cost + (size_t)n * (K8 + 1); unsigned char* sn = split + (size_t)n * (K8 + 1);
+    auto distribute = [&](int j, int& best_a) { double best = 1e300; for (int a = 1; a < j; a++) { const double c = cl[a] + cr[j - a]; if (c < best) { best = c; best_a = a; } } return best; };
+    int a = 1;
+    cn[1] = c8_own_area(n2, n) / root_area + distribute(K8, a); sn[1] = (unsigned char)a;
+    for (int i = 2; i <= K8; i++) {
+        const double d = distribute(i, a), keep = cn[i - 1];
+        if (d < keep) { cn[i] = d; sn[i] = (unsigned char)a; } else { cn[i] = keep; sn[i] = 0; }
+    }
+}   // (cn[] is re-read above through registers only: `keep` comes from the value just stored by this thread)
+__global__ void c8_plan_kernel(const float4* __restrict__ n2, uint32_t n, const int* __restrict__ parent, uint32_t* __restrict__ arrive, double root_area,
+                               double* __restrict__ cost, unsigned char* __restrict__ split) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (c8_child(n2, (int)i, 0) >= 0 || c8_child(n2, (int)i, 1) >= 0) return;          // start at the nodes whose children are both leaves
+    int cur = (int)i;
+    for (uint32_t guard = 0; guard < 4096; guard++) {                                  // (a path to the root is at most the tree's depth long)
+        c8_plan_node(n2, cur, 0.0, root_area, cost, split);
+        const int p = parent[cur];
+        if (p < 0) break;
+        __threadfence();                                                               // this node's costs before the arrival is seen
+        if (atomicAdd(&arrive[p], 1u) + 1u < 2u) break;                                // the other child is still on its way: it will compute p
+        __threadfence();
+        cur = p;
+    }
+}
+
+__global__ void c8_emit_kernel(const float4* __restrict__ n2, const unsigned char* __restrict__ split, const C8Item* __restrict__ items, uint32_t n_items,
+                               float4* __restrict__ n8, C8Emit* __restrict__ emit, uint32_t* __restrict__ cnt_inner, uint32_t* __restrict__ cnt_tris) {
+#pragma clang fp contract(off)
+    const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_items) return;
+    const C8Item w = items[wi];
+    // the roots of the forest below w.node2 that fills eight slots (planned_kids of scene_build.cpp, same visiting order)
+    KidD kids[K8]; int nk = 0;
+    struct Todo { int parent, k, slots; } todo[2 * K8 + 2]; int nt = 0;
+    { const int a = split[(size_t)w.node2 * (K8 + 1) + 1]; todo[nt++] = {w.node2, 1, K8 - a}; todo[nt++] = {w.node2, 0, a}; }
+    while (nt > 0) {
+        const Todo it = todo[--nt];
+        const int c = c8_child(n2, it.parent, it.k);
+        int i = it.slots;
+        if (c >= 0) while (i > 1 && split[(size_t)c * (K8 + 1) + i] == 0) i--;
+        if (c < 0 || i == 1) { if (nk < K8) kids[nk++] = kid_of(n2, it.parent, it.k); continue; }
+        const int a = split[(size_t)c * (K8 + 1) + i];
+        todo[nt++] = {c, 1, i - a}; todo[nt++] = {c, 0, a};
+    }
+    { int m = 0; for (int k = 0; k < nk; k++) if (!(kids[k].code < 0 && (((uint32_t)~kids[k].code) & 7u) == 0u)) { if (m != k) kids[m] = kids[k]; m++; } nk = m; }
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int k = 0; k < nk; k++) for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], kids[k].lo[a]); hi[a] = fmaxf(hi[a], kids[k].hi[a]); }
+    if (nk == 0) for (int a = 0; a < 3; a++) lo[a] = hi[a] = 0.f;
+    int kid_in[8]; for (int sl = 0; sl < 8; sl++) kid_in[sl] = -1;
+    {
+        double cost[8][8]; bool ck[8] = {false, false, false, false, false, false, false, false}, cs[8] = {false, false, false, false, false, false, false, false};
+        for (int k = 0; k < nk; k++) {
+            double cc[3];
+            for (int a = 0; a < 3; a++) cc[a] = 0.5 * ((double)kids[k].lo[a] + kids[k].hi[a]) - 0.5 * ((double)lo[a] + hi[a]);
+            for (int sl = 0; sl < 8; sl++) { double v = 0; for (int a = 0; a < 3; a++) v += ((sl >> a) & 1) ? cc[a] : -cc[a]; cost[k][sl] = v; }
+        }
+        for (int r = 0; r < nk; r++) {
+            int bk = -1, bs = -1; double bv = -INFINITY;
+            for (int k = 0; k < nk; k++) if (!ck[k]) for (int sl = 0; sl < 8; sl++) if (!cs[sl] && (bk < 0 || cost[k][sl] > bv)) { bv = cost[k][sl]; bk = k; bs = sl; }
+            ck[bk] = cs[bs] = true; kid_in[bs] = bk;
+        }
+    }
+    int ebits[3]; double scale[3];
+    for (int a = 0; a < 3; a++) {
+        const double ext = (double)hi[a] - (double)lo[a];
+        int e = ext > 0 ? (int)ceil(log2(ext / 255.0)) : -100;
+        while (ext > 0 && ldexp(255.0, e) < ext) e++;
+        e = e < -126 ? -126 : (e > 127 ? 127 : e);
+        ebits[a] = e; scale[a] = ldexp(1.0, e);
+    }
+    uint32_t q[3][2][2];
+    for (int a = 0; a < 3; a++) { q[a][0][0] = q[a][0][1] = 0xffffffffu; q[a][1][0] = q[a][1][1] = 0u; }
+    uint32_t imask = 0, p0 = 0, p1 = 0;
+    C8Emit em; em.n_inner = em.n_leaf = em.leaf_tris = 0;
+    for (int sl = 0; sl < 8; sl++) {
+        const int k = kid_in[sl]; if (k < 0) continue;
+        for (int a = 0; a < 3; a++) {
+            double ql = floor(((double)kids[k].lo[a] - (double)lo[a]) / scale[a]);
+            double qh = ceil(((double)kids[k].hi[a] - (double)lo[a]) / scale[a]);
+            while (ql > 0 && (float)((double)lo[a] + ql * scale[a]) > kids[k].lo[a]) ql -= 1;
+            while (qh < 255 && (float)((double)lo[a] + qh * scale[a]) < kids[k].hi[a]) qh += 1;
+            ql = fmin(255.0, fmax(0.0, ql)); qh = fmin(255.0, fmax(0.0, qh));
+            const int h = sl >> 2, sh = 8 * (sl & 3);
+            q[a][0][h] = (q[a][0][h] & ~(0xffu << sh)) | ((uint32_t)ql << sh);
+            q[a][1][h] = (q[a][1][h] & ~(0xffu << sh)) | ((uint32_t)qh << sh);
+        }
+        if (kids[k].code >= 0) { imask |= 1u << sl; em.inner2[em.n_inner++] = kids[k].code; }
+        else {
+            const uint32_t leaf = (uint32_t)~kids[k].code, cnt = leaf & 7u;
+            p0 |= (cnt & 1u) << sl; p1 |= ((cnt >> 1) & 1u) << sl;
+            em.leaf_first[em.n_leaf] = leaf >> 3; em.leaf_cnt[em.n_leaf++] = (unsigned char)cnt; em.leaf_tris += cnt;
+        }
+    }
+    auto bf16 = [](int e) { return (uint32_t)(e + 127) << 7; };
+    float4* r = n8 + 5 * (size_t)w.rec;
+    r[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float((bf16(ebits[0]) << 16) | bf16(ebits[1])));
+    r[1] = make_float4(0.f, 0.f, __uint_as_float(bf16(ebits[2]) << 16), __uint_as_float(imask | (p0 << 8) | (p1 << 16) | ((p0 | p1) << 24)));
+    r[2] = make_float4(__uint_as_float(q[0][0][0]), __uint_as_float(q[0][0][1]), __uint_as_float(q[0][1][0]), __uint_as_float(q[0][1][1]));
+    r[3] = make_float4(__uint_as_float(q[1][0][0]), __uint_as_float(q[1][0][1]), __uint_as_float(q[1][1][0]), __uint_as_float(q[1][1][1]));
+    r[4] = make_float4(__uint_as_float(q[2][0][0]), __uint_as_float(q[2][0][1]), __uint_as_float(q[2][1][0]), __uint_as_float(q[2][1][1]));
+    emit[wi] = em; cnt_inner[wi] = em.n_inner; cnt_tris[wi] = em.leaf_tris;
+}
+
+__global__ void c8_number_kernel(const C8Item* __restrict__ items, uint32_t n_items, const C8Emit* __restrict__ emit, const uint32_t* __restrict__ pos_inner,
+                                 const uint32_t* __restrict__ pos_tris, uint32_t rec_base, uint32_t tri_base, float4* __restrict__ n8, C8Item* __restrict__ next,
+                                 const int* __restrict__ order, int* __restrict__ new_order, int* __restrict__ new_first, uint32_t* __restrict__ totals) {
+    const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_items) return;
+    const C8Emit em = emit[wi];
+    const uint32_t cb = rec_base + pos_inner[wi]; uint32_t tb = tri_base + pos_tris[wi];
+    float4* r = n8 + 5 * (size_t)items[wi].rec;
+    float4 r1 = r[1]; r1.x = __uint_as_float(cb); r1.y = __uint_as_float(tb); r[1] = r1;
+    for (uint32_t i = 0; i < em.n_inner; i++) next[pos_inner[wi] + i] = C8Item{em.inner2[i], (int)(cb + i)};
+    for (uint32_t i = 0; i < em.n_leaf; i++) {
+        new_first[em.leaf_first[i]] = (int)tb;
+        for (uint32_t t = 0; t < em.leaf_cnt[i]; t++) new_order[tb++] = order[em.leaf_first[i] + t];
+    }
+    if (wi == n_items - 1) { totals[0] = pos_inner[wi] + em.n_inner; totals[1] = pos_tris[wi] + em.leaf_tris; }
+}
+
+__global__ void c8_remap_kernel(float4* __restrict__ n2, uint32_t n, const int* __restrict__ new_first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 c = n2[4 * (size_t)i + 3];
+    for (int k = 0; k < 2; k++) {
+        const int code = __float_as_int(k == 0 ? c.x : c.y);
+        if (code >= 0) continue;
+        const uint32_t leaf = (uint32_t)~code, first = leaf >> 3, cnt = leaf & 7u;
+        if (cnt == 0) continue;
+        const float v = __int_as_float(~(int)(((uint32_t)new_first[first] << 3) | cnt));
+        if (k == 0) c.x = v; else c.y = v;
+    }
+    n2[4 * (size_t)i + 3] = c;
+}
+}  // namespace
+
+bool gpu_collapse_bvh8(std::vector<f4h>& nodes2, std::vector<int>& order, std::vector<f4h>& nodes8, uint32_t& depth8, std::string& err) {
+    const uint32_t n2 = (uint32_t)(nodes2.size() / 4), nf = (uint32_t)order.size();
+    if (n2 == 0) { err = "gpu_collapse_bvh8: empty binary tree"; return false; }
+    double root_area;
+    {   // own_area(0) of plan_collapse, on the host (same arithmetic)
+        float lo[3], hi[3];
+        const f4h a = nodes2[0], b = nodes2[1], z = nodes2[2];
+        const float l0[3] = {a.x, a.z, z.x}, h0[3] = {a.y, a.w, z.y}, l1[3] = {b.x, b.z, z.z}, h1[3] = {b.y, b.w, z.w};
+        for (int x = 0; x < 3; x++) { lo[x] = std::fmin(l0[x], l1[x]); hi[x] = std::fmax(h0[x], h1[x]); }
+        const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], zz = (double)hi[2] - lo[2];
+        root_area = 2.0 * (x * y + y * zz + zz * x);
+        if (!(root_area > 1e-300)) root_area = 1e-300;
+    }
+    DBuf d_n2, d_n8, d_parent, d_arrive, d_cost, d_split, d_q0, d_q1, d_emit, d_ci, d_ct, d_pi, d_pt, d_order, d_norder, d_nfirst, d_tot, d_tmp;
+    CK(d_n2.alloc(64 * (size_t)n2)); CK(d_n8.alloc(80 * (size_t)n2));            // an 8-wide tree never has more nodes than its binary source
+    CK(d_parent.alloc(4 * (size_t)n2)); CK(d_arrive.alloc(4 * (size_t)n2));
+    CK(d_cost.alloc(sizeof(double) * (size_t)n2 * (K8 + 1))); CK(d_split.alloc((size_t)n2 * (K8 + 1)));
+    CK(d_q0.alloc(sizeof(C8Item) * (size_t)n2)); CK(d_q1.alloc(sizeof(C8Item) * (size_t)n2)); CK(d_emit.alloc(sizeof(C8Emit) * (size_t)n2));
+    CK(d_ci.alloc(4 * (size_t)n2)); CK(d_ct.alloc(4 * (size_t)n2)); CK(d_pi.alloc(4 * (size_t)n2)); CK(d_pt.alloc(4 * (size_t)n2));
+    CK(d_order.alloc(4 * (size_t)nf)); CK(d_norder.alloc(4 * (size_t)nf)); CK(d_nfirst.alloc(4 * ((size_t)nf + 1))); CK(d_tot.alloc(8));
+    CK(hipMemcpy(d_n2.p, nodes2.data(), 64 * (size_t)n2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_order.p, order.data(), 4 * (size_t)nf, hipMemcpyHostToDevice));
+    CK(hipMemset(d_split.p, 0, (size_t)n2 * (K8 + 1))); CK(hipMemset(d_cost.p, 0, sizeof(double) * (size_t)n2 * (K8 + 1))); CK(hipMemset(d_n8.p, 0, 80));
+    CK(hipMemset(d_nfirst.p, 0xff, 4 * ((size_t)nf + 1)));
+    const int B = 128;
+    hipLaunchKernelGGL(c8_parent_kernel, dim3((n2 + B - 1) / B), dim3(B), 0, 0, d_n2.as<float4>(), n2, d_parent.as<int>(), d_arrive.as<uint32_t>());
+    hipLaunchKernelGGL(c8_plan_kernel, dim3((n2 + B - 1) / B), dim3(B), 0, 0, d_n2.as<float4>(), n2, d_parent.as<int>(), d_arrive.as<uint32_t>(), root_area, d_cost.as<double>(),
+                       d_split.as<unsigned char>());
+    CK(hipGetLastError());
+    size_t scan_bytes = 0;
+    CK(rocprim::exclusive_scan(nullptr, scan_bytes, d_ci.as<uint32_t>(), d_pi.as<uint32_t>(), 0u, (size_t)n2, rocprim::plus<uint32_t>()));
+    CK(d_tmp.alloc(scan_bytes));
+    const C8Item root{0, 0};
+    CK(hipMemcpy(d_q0.p, &root, sizeof root, hipMemcpyHostToDevice));
+    uint32_t n_items = 1, n_rec = 1, n_tri = 0; depth8 = 0;
+    C8Item* cur = d_q0.as<C8Item>(); C8Item* nxt = d_q1.as<C8Item>();
+    while (n_items > 0) {
+        if (++depth8 > 256) { err = "gpu_collapse_bvh8: tree too deep"; return false; }
+        const dim3 g((n_items + B - 1) / B);
+        hipLaunchKernelGGL(c8_emit_kernel, g, dim3(B), 0, 0, d_n2.as<float4>(), d_split.as<unsigned char>(), cur, n_items, d_n8.as<float4>(), d_emit.as<C8Emit>(), d_ci.as<uint32_t>(),
+                           d_ct.as<uint32_t>());
+        CK(hipGetLastError());
+        CK(rocprim::exclusive_scan(d_tmp.p, scan_bytes, d_ci.as<uint32_t>(), d_pi.as<uint32_t>(), 0u, (size_t)n_items, rocprim::plus<uint32_t>()));
+        CK(rocprim::exclusive_scan(d_tmp.p, scan_bytes, d_ct.as<uint32_t>(), d_pt.as<uint32_t>(), 0u, (size_t)n_items, rocprim::plus<uint32_t>()));
+        hipLaunchKernelGGL(c8_number_kernel, g, dim3(B), 0, 0, cur, n_items, d_emit.as<C8Emit>(), d_pi.as<uint32_t>(), d_pt.as<uint32_t>(), n_rec, n_tri, d_n8.as<float4>(), nxt,
+                           d_order.as<int>(), d_norder.as<int>(), d_nfirst.as<int>(), d_tot.as<uint32_t>());
+        CK(hipGetLastError());
+        uint32_t tot[2];
+        CK(hipMemcpy(tot, d_tot.p, 8, hipMemcpyDeviceToHost));
+        if ((size_t)n_rec + tot[0] > n2 || (size_t)n_tri + tot[1] > nf) { err = "gpu_collapse_bvh8: inconsistent counts (internal error)"; return false; }
+        n_rec += tot[0]; n_tri += tot[1]; n_items = tot[0];
+        C8Item* t = cur; cur = nxt; nxt = t;
+    }
+    if (n_tri != nf) { err = "gpu_collapse_bvh8: not every triangle was placed (internal error)"; return false; }
+    hipLaunchKernelGGL(c8_remap_kernel, dim3((n2 + B - 1) / B), dim3(B), 0, 0, d_n2.as<float4>(), n2, d_nfirst.as<int>());
+    CK(hipGetLastError());
+    nodes8.resize(5 * (size_t)n_rec);
+    CK(hipMemcpy(nodes8.data(), d_n8.p, 80 * (size_t)n_rec, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(nodes2.data(), d_n2.p, 64 * (size_t)n2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(order.data(), d_norder.p, 4 * (size_t)nf, hipMemcpyDeviceToHost));
+    return true;
+}

@@ -217,6 +217,10 @@ static void fill_wide_info(mcpt_scene_info& in, const HostScene& hs) {
     in.wide_depth = hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth;
     in.traversal_bytes = (hs.nodes4.size() + hs.nodes8.size() + hs.tri_isect.size()) * sizeof(f4h);
     for (int a = 0; a < 3; a++) in.centre[a] = hs.centre[a];
+    uint64_t h = 1469598103934665603ull;                                  // FNV-1a, 4 bytes at a time
+    auto mix = [&](const void* p, size_t bytes) { const uint32_t* w = static_cast<const uint32_t*>(p); for (size_t i = 0; i < bytes / 4; i++) { h ^= w[i]; h *= 1099511628211ull; } };
+    mix(hs.nodes8.data(), hs.nodes8.size() * sizeof(f4h)); mix(hs.nodes4.data(), hs.nodes4.size() * sizeof(f4h)); mix(hs.tri_face.data(), hs.tri_face.size() * 4);
+    in.wide_tree_hash = h;
 }
 
 extern "C" {
@@ -278,7 +282,8 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             if (!(lbvh ? gpu_build_bvh2(boxes, n, g, berr) : gpu_build_ploc(boxes, n, g, berr))) return false;
             nodes.swap(g.nodes); order.assign(g.order.begin(), g.order.end()); depth = g.depth; max_leaf = g.max_leaf;
             return true;
-        }, env_u32("MCPT_HOST_COLLAPSE", 0) ? Collapse4Fn(nullptr) : Collapse4Fn(gpu_collapse_bvh4));
+        }, env_u32("MCPT_HOST_COLLAPSE", 0) ? Collapse4Fn(nullptr) : Collapse4Fn(gpu_collapse_bvh4),
+           env_u32("MCPT_HOST_COLLAPSE", 0) ? Collapse8Fn(nullptr) : Collapse8Fn(gpu_collapse_bvh8));
         if (st != MCPT_OK) return fail(st, err);
         if (env_u32("MCPT_VALIDATE_BVH", 0)) { const std::string bad = validate_wide_bvh(hs); if (!bad.empty()) return fail(MCPT_ERR_HIP, "device-built BVH failed validation: " + bad); }
     } else {

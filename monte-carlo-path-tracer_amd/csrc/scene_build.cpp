@@ -575,7 +575,8 @@ std::string validate_bvh8(const HostScene& hs) {
     return "";
 }
 
-mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh, const Collapse4Fn& custom_collapse) {
+mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh, const Collapse4Fn& custom_collapse,
+                             const Collapse8Fn& custom_collapse8) {
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
     if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }
     if (d->camera.width <= 0 || d->camera.height <= 0) { err = "camera width/height must be positive"; return MCPT_ERR_INVALID_ARG; }
@@ -706,7 +707,8 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     out.binary_ok = out.bvh_depth <= uint32_t(MCPT_STACK_DEPTH - 1);
     if (!out.binary_ok && !out.allow_deep_binary) { err = "BVH depth exceeds traversal stack"; return MCPT_ERR_BVH_DEPTH; }
     out.nodes4.clear(); out.nodes8.clear(); out.bvh4_depth = out.bvh8_depth = 0;
-    if (out.bvh_width == 8) build_bvh8(out, order);                       // (defines the leaf order: `order` and the binary leaf codes are rewritten)
+    if (out.bvh_width == 8 && custom_collapse8) { if (!custom_collapse8(out.nodes, order, out.nodes8, out.bvh8_depth, err)) return MCPT_ERR_HIP; }
+    else if (out.bvh_width == 8) build_bvh8(out, order);                  // (defines the leaf order: `order` and the binary leaf codes are rewritten)
     else if (custom_collapse) { if (!custom_collapse(out.nodes, out.nodes4, out.bvh4_depth, err)) return MCPT_ERR_HIP; }
     else build_bvh4(out);
     if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] %u-wide collapse done at %.0f ms (%zu nodes, depth %u)\n", out.bvh_width,

@@ -40,11 +40,13 @@ using BvhBuildFn = std::function<bool(const float* boxes, uint32_t n, std::vecto
 
 // Optional replacement for the host's 4-wide collapse + quantisation (bvh_gpu.hip): binary nodes (renumbered, root = 0) in, nodes4 + depth out.
 using Collapse4Fn = std::function<bool(const std::vector<f4h>& nodes2, std::vector<f4h>& nodes4, uint32_t& depth4, std::string& err)>;
+// ... and of the 8-wide collapse (bvh_gpu.hip: gpu_collapse_bvh8): rewrites the binary tree's leaf codes and the leaf order like build_bvh8 does.
+using Collapse8Fn = std::function<bool(std::vector<f4h>& nodes2, std::vector<int>& order, std::vector<f4h>& nodes8, uint32_t& depth8, std::string& err)>;
 
 // Validates the description (indices in range, sizes non-zero), flattens faces, collects lights, builds the BVH.
 // Returns MCPT_OK or an error code with `err` filled.
 mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh = nullptr,
-                             const Collapse4Fn& custom_collapse = nullptr);
+                             const Collapse4Fn& custom_collapse = nullptr, const Collapse8Fn& custom_collapse8 = nullptr);
 
 // Host-side soundness check of the quantised 4-wide tree (empty string = sound); run by mcpt_check_scene.
 std::string validate_bvh4(const HostScene& hs);

@@ -134,3 +134,22 @@ def test_both_device_builders_are_sound_and_ploc_is_the_better_tree(pkg, paths, 
             assert cost["lbvh"] <= 2.0 * cost["host"]
     finally:
         os.environ.pop("MCPT_GPU_BVH", None)
+
+
+@pytest.mark.parametrize("name,kw,res", [("cornell-box-small", {}, (48, 48)), ("veach-mis", {"light_lon": 12, "light_lat": 6, "plate_cells": 4}, (64, 36)),
+                                         ("bathroom2", {"detail": 24, "tex_size": 32}, (64, 36)), ("bathroom2", {"detail": 100, "tex_size": 32}, (64, 36))])
+def test_device_collapse_reproduces_the_host_collapse(pkg, name, kw, res):
+    """gpu_collapse_bvh8 (bvh_gpu.hip) against build_bvh8 (scene_build.cpp) on the same device-built binary tree: the same dynamic programme in the
+    same double arithmetic, the same octant slots, the same level-by-level numbering -- so the 8-wide records and the leaf order must be the
+    host's bit for bit (mcpt_scene_info.wide_tree_hash covers both), and a deterministic render the same film."""
+    scene = pkg.scenes.SCENES[name](res[0], res[1], **kw)
+    out = []
+    for host_collapse in (False, True):
+        if host_collapse: os.environ["MCPT_HOST_COLLAPSE"] = "1"
+        try:
+            r = _gpu_tree_renderer(pkg, scene, max_depth=5, flags=pkg.FLAG_DETERMINISTIC)
+        finally:
+            os.environ.pop("MCPT_HOST_COLLAPSE", None)
+        i = r.info(); r.render(4, seed=3); out.append(((i.wide_nodes, i.wide_depth, i.wide_tree_hash), r.read_accum())); r.close()
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])

@@ -1198,3 +1198,19 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
         out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["film_count_plane_ok"] is True
         assert out["scaling"] == ("strong" if shard == "tiles" else "weak") and out["value"] > 0
+
+
+def test_path_pools_grow_with_the_job_and_keep_the_film_exact(pkg):
+    """The path pools are allocated by the first render call and grown to the largest job seen (mcpt_api.cpp: ensure_pool): a context that
+    rendered one sample of a small film holds a small pool; a later, larger job re-allocates it between two calls -- nothing of a job lives in
+    the pool across calls, so the film after both equals a fresh context's, and device_bytes says what is held."""
+    scene = pkg.scenes.cornell_box_small(160, 120)
+    flags = pkg.FLAG_DETERMINISTIC
+    r = pkg.Renderer(scene, max_depth=5, flags=flags)
+    b0 = r.info().device_bytes
+    r.render(1, seed=4); b1 = r.info().device_bytes
+    r.render(40, seed=4, first_sample=1); b2 = r.info().device_bytes; grown = r.read_accum()
+    r.render(1, seed=4, first_sample=41); b3 = r.info().device_bytes; r.close()       # a smaller job afterwards: the pool stays
+    assert b0 < b1 <= b2 == b3 and b1 - b0 < 64 << 20                                 # (one slot per pixel: 160 x 120 x 164 B, not 2.75 GB)
+    f = pkg.Renderer(scene, max_depth=5, flags=flags); f.render(41, seed=4); fresh = f.read_accum(); f.close()
+    assert np.array_equal(grown[..., 3], fresh[..., 3]) and np.allclose(grown, fresh, rtol=2e-6, atol=1e-6)
