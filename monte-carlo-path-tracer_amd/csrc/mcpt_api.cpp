@@ -597,13 +597,13 @@ mcpt_status mcpt_render_tiles(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32
     if (ctx->opts.flags & MCPT_FLAG_DETERMINISTIC) spi = spp;               // one lane owns a pixel for the whole call
     else if (spi == 0) {
         if (ctx->use_wavefront) {
-            // auto: one sample per item unless (a) the image is so small that many pool slots would hammer the same pixel's film
-            // atomics at once, or (b) the item count would overflow the cursor range.  Short items keep the end-of-render drain
-            // short (a slot works its item off sample after sample: 8-sample items cost 2.7 % at 1024 spp on the bench workload)
-            // and cost nothing any more now that items come from sharded cursors with one atomic per block.
-            const uint64_t slots = uint64_t(ctx->pool_cap) * ctx->lanes.size(), pixels = tiles * 64;   // the pixels this call owns
+            // auto: one sample per item, longer ones only to keep the item count in the cursors' range.  Short items keep the end-of-render
+            // drain short (a slot works its item off sample after sample: 8-sample items cost 2.7 % at 1024 spp on the bench workload).
+            // Rounds 1-2 also grew the items when many pool slots would share a film pixel (more than 32 per pixel), for fear of the film's
+            // float atomics; measured in round 3 that rule was the problem, not the atomics: 64 x 64 x 4096 spp 88 -> 17 ms without it
+            // (4 096 slots per pixel), 16 x 16 x 16 384 spp 49 -> 9 ms, 256 x 256 x 1024 spp 60 -> 51 ms, and an interleaved-tile share of
+            // the bench job (1/8 of the pixels) 72 -> 58 ms -- the atomics execute at the memory side and 10^4 adders per address are fine.
             spi = 1;
-            while (spi < 64 && slots > pixels * 32ull * spi) spi <<= 1;
             while (tiles * ((spp + spi - 1) / spi) > 0x3ffffffull && spi < spp) spi <<= 1;
         } else {
             // megakernel: long enough that per-item overheads vanish, short enough that the work balances across the chip
