@@ -165,7 +165,8 @@ static mcpt_status finish_ctx(mcpt_ctx* c) {
         if ((e = hipGetDeviceProperties(&prop, c->device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
         c->n_cus = prop.multiProcessorCount;
         c->pool_cap = 1u << std::min(26u, env_u32("MCPT_WF_POOL_LOG2", 23));
-        if (c->pool_cap < 2048) c->pool_cap = 2048;
+        c->pool_cap = env_u32("MCPT_WF_POOL_SLOTS", c->pool_cap) & ~uint32_t(16 * WF_SHADE_BLOCK - 1);   // (developer knob: any multiple of 4096 slots)
+        if (c->pool_cap < 4096) c->pool_cap = 4096;
         c->items_per_slot = std::max(1u, env_u32("MCPT_WF_ITEMS_PER_SLOT", 1));
         c->tune.refill_at = env_u32("MCPT_WF_REFILL", 28); c->tune.leaf_at = env_u32("MCPT_WF_LEAF", 16);
         c->tune.inner_keep = env_u32("MCPT_WF_INNER", 24); c->tune.policy = env_u32("MCPT_WF_POLICY", 0); c->tune.pend_cap = 48;      // speculative traversal: refined below once the scene's size is known
@@ -194,7 +195,11 @@ static mcpt_status finish_ctx(mcpt_ctx* c) {
                 for (auto& ev : L.chk_ev) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
                 if ((e = hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
                 if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-                if ((e = L.ovf_buf.alloc(size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_bytes_per_lane(c->wide_depth, c->wide_width))) != hipSuccess)
+                // the global overflow area of the traversal stack is sized from the wide tree's depth (2 x depth + 3 entries of 8 B per trace lane): a
+                // pathologically deep device-built tree (depth in the hundreds) would ask for a GB per sub-pipeline -- refuse instead of allocating it
+                const size_t ovf_bytes = size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_bytes_per_lane(c->wide_depth, c->wide_width);
+                if (ovf_bytes > (size_t(512) << 20)) return fail(MCPT_ERR_BVH_DEPTH, "wide BVH of depth " + std::to_string(c->wide_depth) + " needs a traversal-stack overflow area of " + std::to_string(ovf_bytes >> 20) + " MB per sub-pipeline: build the tree with the host builder (no MCPT_FLAG_GPU_BVH_BUILD)");
+                if ((e = L.ovf_buf.alloc(ovf_bytes)) != hipSuccess)
                     return bail(e, "alloc stack overflow area");
             }
         }
