@@ -1138,8 +1138,8 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     const bool use_a = !(any && ta == htri), use_b = i + 1 < cnt && !(any && tb == htri);   // any-hit rays keep their `skip` triangle in htri
                     const float4* T = (const float4*)((const char*)sc.tri_isect + (uint32_t)ta * 48u);   // (n_tris < 2^28 x 48 B would overflow 32 bits: checked at launch)
                     // triangle a is fetched whether or not it is the ray's `skip` triangle (its test is skipped, not its load: no zero-initialised
-                    // merge registers, -1 ... -2 % step time); fetching b unconditionally as well costs four more registers (82: one wave per
-                    // SIMD less) and 10 % -- S-cornell 203.6 (a) / 225.1 (a + b) / 205.1 ms (neither)
+                    // merge registers, -1 ... -2 % step time); fetching b unconditionally as well is slower even where the registers are there
+                    // (68 without the SLP vectoriser: 204.2 vs 201.4 ms -- half of the leaves have one triangle and the load is not free)
                     const float4 v0a = T[0], e1a = T[1], e2a = T[2];
                     float4 v0b = make_float4(0, 0, 0, 0), e1b = v0b, e2b = v0b;
                     if (use_b) { v0b = T[3]; e1b = T[4]; e2b = T[5]; }
