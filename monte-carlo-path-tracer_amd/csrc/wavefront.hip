@@ -1132,8 +1132,26 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 t_y &= ~(1u << (24u + s));
                 if ((t_y >> 24) == 0u) t_y = 0u;
                 bool done = false;
+                // Both acceptance rules (Triangle::hit / Triangle::isIntersect, see tri_accept_* in pt_device.h) as ONE predicate and the hit-state
+                // update as four selects: spelled with short-circuit `&&` and `if` the compiler built a branch per term and copied the hit state
+                // (tmax, triangle, u, v) at every join -- ~12 of ~64 VALU issues per triangle.  `u <= 1` of the any-hit rule is implied by
+                // v >= 0 and fl(u + v) <= 1 (rounding is monotone) and is not tested separately.
+                auto leaf_test = [&](const float4 v0, const float4 e1, const float4 e2, const int ti, const bool use) __attribute__((always_inline)) {
+                    const TriTest r = tri_test(v0, e1, e2, o, d);
+                    const bool a_ok = fabsf(r.a) >= (any ? 1e-6f : 1e-5f);
+                    const bool uv_ok = (r.u >= 0.0f) & (r.v >= 0.0f) & (any ? (r.u + r.v <= 1.0f) : ((1.0f - r.u - r.v) >= 0.0f));
+                    const bool t_ok = (r.t >= 1e-4f) & (any ? (r.t <= tmax) : ((r.t < tmax) | ((r.t == tmax) & (ti < (htri & HIT_TRI_MASK)))));
+                    const bool acc = use & a_ok & uv_ok & t_ok;
+                    const bool upd = acc & !any;
+                    tmax = upd ? r.t : tmax; hu = upd ? r.u : hu; hv = upd ? r.v : hv;
+                    htri = upd ? (ti | __float_as_int(v0.w)) : htri;             // v0.w = lobe class << 28
+                    blocked = blocked | (acc & any);
+                    return acc & any;
+                };
+                constexpr bool one_pair = MCPT_LEAF_MAX <= 2;            // a leaf holds at most MCPT_LEAF_MAX triangles: with two the pair loop is one pass
+                uint32_t i = 0;
 #pragma unroll 1
-                for (uint32_t i = 0; i < cnt && !done; i += 2) {
+                do {
                     const int ta = (int)(first + i), tb = ta + 1;
                     const bool use_a = !(any && ta == htri), use_b = i + 1 < cnt && !(any && tb == htri);   // any-hit rays keep their `skip` triangle in htri
                     const float4* T = (const float4*)((const char*)sc.tri_isect + (uint32_t)ta * 48u);   // (n_tris < 2^28 x 48 B would overflow 32 bits: checked at launch)
@@ -1146,17 +1164,10 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 #ifndef WF_SCHED_STATS
                     if (COUNT) n_tri += (use_a ? 1u : 0u) + (use_b ? 1u : 0u);
 #endif
-                    if (use_a) {
-                        const TriTest r = tri_test(v0a, e1a, e2a, o, d);
-                        if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }                     // Triangle::isIntersect
-                        else if (tri_accept_closest_tie(r, 1e-4f, tmax, ta, htri & HIT_TRI_MASK)) { tmax = r.t; htri = ta | __float_as_int(v0a.w); hu = r.u; hv = r.v; }   // Triangle::hit; v0.w = lobe class << 28
-                    }
-                    if (use_b && !done) {
-                        const TriTest r = tri_test(v0b, e1b, e2b, o, d);
-                        if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }
-                        else if (tri_accept_closest_tie(r, 1e-4f, tmax, tb, htri & HIT_TRI_MASK)) { tmax = r.t; htri = tb | __float_as_int(v0b.w); hu = r.u; hv = r.v; }
-                    }
-                }
+                    done = leaf_test(v0a, e1a, e2a, ta, use_a);
+                    if (__ballot(use_b) != 0) done = done | leaf_test(v0b, e1b, e2b, tb, use_b & !done);
+                    i += 2;
+                } while (!one_pair && i < cnt && !done);
                 if (done) { cur_y = 0u; t_y = 0u; }                      // any-hit: stop at the first occluder
                 else WF8_PARK()                                          // the group is worked off and another one was waiting on top of the stack
             }
