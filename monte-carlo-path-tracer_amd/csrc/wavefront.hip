@@ -1045,7 +1045,13 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         const int n_idle = 64 - n_inner - n_leaf;
 
         const int most = n_inner > n_leaf ? n_inner : n_leaf;
-        if ((n_inner + n_leaf == 0) || (!exhausted && (greedy ? n_idle >= most : n_idle >= (int)tune.refill_at))) {
+        // Which block runs this round -- as an opaque scalar, so that the three blocks stay three `if` regions IN SEQUENCE: written as
+        // if / continue the compiler gave the loop one latch with a three-way merge of the ten state registers two blocks modify, and copied
+        // all ten into the merge registers at the end of every block and back out of them at the latch (20 v_mov per scheduler round).
+        uint32_t sel = ((n_inner + n_leaf == 0) || (!exhausted && (greedy ? n_idle >= most : n_idle >= (int)tune.refill_at))) ? 0u
+                     : (n_leaf >= (int)tune.leaf_at || n_inner == 0 || (speculate && n_pend >= (int)tune.pend_cap)) ? 1u : 2u;
+        asm volatile("" : "+s"(sel));
+        if (sel == 0u) {
             // ------------------------------------------------------------------ refill block
 #ifdef WF_SCHED_STATS
             x_refill++; l_refill += (uint32_t)n_idle;
@@ -1116,10 +1122,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
             }
             WF_TICK(t_refill)
             if (exhausted && __ballot(have) == 0) break;
-            continue;
         }
 
-        if (n_leaf >= (int)tune.leaf_at || n_inner == 0 || (speculate && n_pend >= (int)tune.pend_cap)) {
+        if (sel == 1u) {
             // ------------------------------------------------------------------ leaf block: every lane with a parked leaf group tests ONE of its leaves
 #ifdef WF_SCHED_STATS
             x_leaf++; if (at_leaf) n_tri++;
@@ -1172,9 +1177,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 else WF8_PARK()                                          // the group is worked off and another one was waiting on top of the stack
             }
             WF_TICK(t_leaf)
-            continue;
         }
 
+        if (sel != 2u) continue;
         // ---------------------------------------------------------------------- inner-node block: one 80-B record = eight child boxes
         int keep = (int)tune.inner_keep;
         order_matters = __ballot(have && !any) != 0;
