@@ -1164,8 +1164,8 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     // merge registers, -1 ... -2 % step time); fetching b unconditionally as well is slower even where the registers are there
                     // (68 without the SLP vectoriser: 204.2 vs 201.4 ms -- half of the leaves have one triangle and the load is not free)
                     const float4 v0a = T[0], e1a = T[1], e2a = T[2];
-                    float4 v0b = make_float4(0, 0, 0, 0), e1b = v0b, e2b = v0b;
-                    if (use_b) { v0b = T[3]; e1b = T[4]; e2b = T[5]; }
+                    const float4* Tb = use_b ? T + 3 : T;                // (a lane without b reads a's record again: the same cache lines, no merge registers)
+                    const float4 v0b = Tb[0], e1b = Tb[1], e2b = Tb[2];
 #ifndef WF_SCHED_STATS
                     if (COUNT) n_tri += (use_a ? 1u : 0u) + (use_b ? 1u : 0u);
 #endif
