@@ -176,11 +176,26 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         __syncthreads();
         // exclusive prefix of the slot's (key, wave) counter over the [key][wave] table, summed by every thread for itself (20 broadcast LDS
         // reads) -- a serial scan by one thread between two barriers cost a barrier
-        uint32_t before_me = 0;
         const uint32_t my_cell = skey * (WF_SHADE_BLOCK / 64) + wv;
+#ifdef MCPT_SHADE_SERIAL_PREFIX      // A/B: every thread sums the table itself (20 broadcast reads, 60 VALU issues per wave)
+        uint32_t before_me = 0;
 #pragma unroll
         for (uint32_t i = 0; i < K_COUNT * (WF_SHADE_BLOCK / 64); i++) before_me += i < my_cell ? s_kcnt[i] : 0u;
-        s_perm[before_me + my_rank] = tid | (key << 16);
+#else
+        // ... as a wave scan: lane i < 20 holds cell i, five DPP adds make the inclusive prefix over lanes 0..31 (row_shr 1/2/4/8 inside
+        // each row of 16 lanes, row_bcast:15 carries row 0's total into row 1), and every lane fetches the entry of its own cell with one
+        // ds_bpermute -- ~15 instead of ~60 VALU issues per wave, in a kernel half of whose issues are this prologue and the epilogue
+        static_assert(K_COUNT * (WF_SHADE_BLOCK / 64) <= 32, "the scan covers two DPP rows");
+        const uint32_t cell_cnt = lane < K_COUNT * (WF_SHADE_BLOCK / 64) ? s_kcnt[lane] : 0u;
+        int inc = (int)cell_cnt;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);      // row_shr:1  (lanes shifted in from outside the row read 0)
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);      // row_shr:2
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);      // row_shr:4
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);      // row_shr:8
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3 (other rows add the `old` operand, 0)
+        const uint32_t before_me = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_cell << 2), inc - (int)cell_cnt);   // exclusive prefix of my cell
+#endif
+        s_perm[(before_me + my_rank) & (WF_SHADE_BLOCK - 1u)] = tid | (key << 16);
         __syncthreads();
     }
 #ifdef MCPT_SHADE_PERM_TEST     // diagnostic: a class-blind interleave -- every wave touches every line of the window, no sorting benefit
