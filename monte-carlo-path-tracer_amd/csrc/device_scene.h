@@ -24,6 +24,9 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
+// 8-wide tree: every quantised child plane lies at least this many quantisation steps outside the child's box (build_bvh8,
+// gpu_collapse_bvh8) -- the margin the trace kernel's fp16-mix plane arithmetic needs (wavefront.hip, WF8_CHILD)
+#define MCPT_Q_MARGIN (1.0 / 1024.0)
 #ifndef MCPT_LEAF_MAX
 #define MCPT_LEAF_MAX 2
 #endif

@@ -407,13 +407,21 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
                 ck[bk] = cs[bs] = true; kid_in[bs] = bk;
             }
         }
+        // The frame: a power-of-two step and an origin a little BELOW the lowest child bound, so that every quantised plane -- also those of
+        // children that touch the node's faces -- lies at least MCPT_Q_MARGIN steps outside its box: the trace kernel forms its plane
+        // distances as (1024 + q) a + (b - 1024 a), whose offset carries a rounding of up to 6e-5 steps (wavefront.hip, WF8_CHILD).
         int ebits[3]; double scale[3];
         for (int a = 0; a < 3; a++) {
             const double ext = double(hi[a]) - double(lo[a]);
             int e = ext > 0 ? int(std::ceil(std::log2(ext / 255.0))) : -100;
-            while (ext > 0 && std::ldexp(255.0, e) < ext) e++;                       // guard log2 rounding
             e = std::max(-126, std::min(127, e));
-            ebits[a] = e; scale[a] = std::ldexp(1.0, e);
+            float lof = lo[a];
+            for (;; e++) {
+                const double sc = std::ldexp(1.0, e), lf = double(lo[a]) - 2.0 * MCPT_Q_MARGIN * sc;
+                lof = float(lf); if (double(lof) > lf) lof = std::nextafterf(lof, -INFINITY);
+                if (!(ext > 0) || e >= 127 || double(hi[a]) - double(lof) + 2.0 * MCPT_Q_MARGIN * sc <= 255.0 * sc) break;
+            }
+            lo[a] = lof; ebits[a] = e; scale[a] = std::ldexp(1.0, e);
         }
         // empty slots keep an inverted box (lo 255, hi 0): no ray interval survives it
         uint32_t q[3][2][2];                                                         // [axis][lo / hi][slots 0-3 / 4-7]
@@ -423,8 +431,8 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
         for (int sl = 0; sl < 8; sl++) {
             const int k = kid_in[sl]; if (k < 0) continue;
             for (int a = 0; a < 3; a++) {
-                double ql = std::floor((double(kids[k].box.lo[a]) - double(lo[a])) / scale[a]);
-                double qh = std::ceil((double(kids[k].box.hi[a]) - double(lo[a])) / scale[a]);
+                double ql = std::floor((double(kids[k].box.lo[a]) - double(lo[a])) / scale[a] - MCPT_Q_MARGIN);
+                double qh = std::ceil((double(kids[k].box.hi[a]) - double(lo[a])) / scale[a] + MCPT_Q_MARGIN);
                 while (ql > 0 && float(double(lo[a]) + ql * scale[a]) > kids[k].box.lo[a]) ql -= 1;      // the fp32 reconstruction must still enclose the child box
                 while (qh < 255 && float(double(lo[a]) + qh * scale[a]) < kids[k].box.hi[a]) qh += 1;
                 ql = std::min(255.0, std::max(0.0, ql)); qh = std::min(255.0, std::max(0.0, qh));
@@ -549,6 +557,7 @@ std::string validate_bvh8(const HostScene& hs) {
             const bool inner = (imask >> sl) & 1u; const uint32_t cnt = ((p0 >> sl) & 1u) + 2u * ((p1 >> sl) & 1u);
             const uint32_t below = (1u << sl) - 1u, sh = 8u * (sl & 3);
             Item ch;
+            float own_lo[3], own_hi[3];
             bool inverted = false;
             for (int a = 0; a < 3; a++) {
                 const uint32_t wl = as_u32(sl < 4 ? Q[a].x : Q[a].y), wh = as_u32(sl < 4 ? Q[a].z : Q[a].w);
@@ -556,6 +565,7 @@ std::string validate_bvh8(const HostScene& hs) {
                 if (qlo > qhi) inverted = true;
                 const float lo = org[a] + qlo * sc[a], hi = org[a] + qhi * sc[a];
                 ch.lo[a] = std::max(it.lo[a], lo); ch.hi[a] = std::min(it.hi[a], hi);
+                own_lo[a] = lo; own_hi[a] = hi;
             }
             if (!inner && cnt == 0) { if (!inverted) return "an empty slot has a box a ray could enter"; continue; }
             if (inverted) return "an occupied slot has an inverted box";
@@ -566,8 +576,12 @@ std::string validate_bvh8(const HostScene& hs) {
                 if (seen[t]++) return "triangle referenced twice";
                 const f4h v0 = hs.tri_isect[3 * size_t(t)], e1 = hs.tri_isect[3 * size_t(t) + 1], e2 = hs.tri_isect[3 * size_t(t) + 2];
                 const float P[3][3] = {{v0.x, v0.y, v0.z}, {v0.x + e1.x, v0.y + e1.y, v0.z + e1.z}, {v0.x + e2.x, v0.y + e2.y, v0.z + e2.z}};
-                for (int c = 0; c < 3; c++) for (int a = 0; a < 3; a++)
+                for (int c = 0; c < 3; c++) for (int a = 0; a < 3; a++) {
                     if (!(P[c][a] >= ch.lo[a] && P[c][a] <= ch.hi[a])) return "triangle " + std::to_string(t) + " sticks out of a quantised box on its path";
+                    // the leaf's own planes keep MCPT_Q_MARGIN steps of distance (half of it asked for here, less the fp32 rounding of this very reconstruction)
+                    const float slack = float(0.5 * MCPT_Q_MARGIN) * sc[a] - 4.0f * std::max(std::fabs(org[a]), std::fabs(P[c][a])) * 1.2e-7f;
+                    if (!(P[c][a] - own_lo[a] >= slack && own_hi[a] - P[c][a] >= slack)) return "triangle " + std::to_string(t) + " closer than the quantisation margin to a plane of its leaf box";
+                }
             }
         }
     }

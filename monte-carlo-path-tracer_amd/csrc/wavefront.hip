@@ -898,11 +898,17 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #ifndef MCPT_TOP_NODES8
 #define MCPT_TOP_NODES8 160         // records numbered breadth-first by the builder; 160 x 80 B = 12.5 KB of LDS
 #endif
+// One child box.  The six plane bytes reach the fma as the low bytes of fp16 values 1024 + q (0x64qq: one v_perm_b32 makes two of them) and
+// v_fma_mix_f32 converts on the way in -- a perm per two planes + one fma per plane instead of a v_cvt_f32_ubyte + an fma per plane
+// (-3 of 16 VALU issues per child).  The 1024 is folded into the plane offset: t = (1024 + q) a + (b - 1024 a); that offset's rounding
+// (<= 2^-24 x 1024 a = 6e-5 quantisation steps) is covered by the builder, which keeps every quantised plane >= 1e-3 steps outside the box.
+typedef _Float16 wf_h2 __attribute__((ext_vector_type(2)));
+#define WF8_H(V, K) ((float)(V)[(K) & 1])
 #define WF8_CHILD(K, NX, FX, NY, FY, NZ, FZ)                                                                                         \
         {                                                                                                                    \
-            const float t0x = fmaf((float)((NX >> (8 * (K & 3))) & 0xffu), ax, bx), t1x = fmaf((float)((FX >> (8 * (K & 3))) & 0xffu), ax, bx); \
-            const float t0y = fmaf((float)((NY >> (8 * (K & 3))) & 0xffu), ay, by), t1y = fmaf((float)((FY >> (8 * (K & 3))) & 0xffu), ay, by); \
-            const float t0z = fmaf((float)((NZ >> (8 * (K & 3))) & 0xffu), az, bz), t1z = fmaf((float)((FZ >> (8 * (K & 3))) & 0xffu), az, bz); \
+            const float t0x = fmaf(WF8_H(NX, K), ax, bx), t1x = fmaf(WF8_H(FX, K), ax, bx);                                  \
+            const float t0y = fmaf(WF8_H(NY, K), ay, by), t1y = fmaf(WF8_H(FY, K), ay, by);                                  \
+            const float t0z = fmaf(WF8_H(NZ, K), az, bz), t1z = fmaf(WF8_H(FZ, K), az, bz);                                  \
             const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 1e-4f));                                                      \
             const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));                                                       \
             /* m = 2 m + (tn <= tf): the compare's carry shifted in by ONE add-with-carry (slot 7 first, so slot s ends up in bit s) */ \
@@ -993,6 +999,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     // eight boxes and updates the stack.
     v4f R0, R1, R2, R3, R4;
     bool order_matters = true;
+    uint32_t k64 = 0x64646464u; asm volatile("" : "+v"(k64));      // the fp16 exponent byte of WF8_CHILD's plane values, pinned in a VGPR (v_perm_b32 has one constant-bus operand: the selector)
     auto inner_issue = [&]() __attribute__((always_inline)) {
         // next child of the group on top: lowest pending bit j = slot j ^ oct; its record = base + rank among the inner slots
         const uint32_t j = (uint32_t)__builtin_ctz(cur_y);
@@ -1005,7 +1012,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     auto inner_consume = [&]() __attribute__((always_inline)) {
         const uint32_t sxy = __float_as_uint(R0.w), masks = __float_as_uint(R1.w);
         const float ax = __uint_as_float(sxy & 0xffff0000u) * idx, ay = __uint_as_float(sxy << 16) * idy, az = __uint_as_float(__float_as_uint(R1.z) & 0xffff0000u) * idz;
-        const float bx = fmaf(R0.x, idx, nox), by = fmaf(R0.y, idy, noy), bz = fmaf(R0.z, idz, noz);
+        const float bx = fmaf(-1024.0f, ax, fmaf(R0.x, idx, nox)), by = fmaf(-1024.0f, ay, fmaf(R0.y, idy, noy)), bz = fmaf(-1024.0f, az, fmaf(R0.z, idz, noz));   // (plane offset - 1024 a: see WF8_CHILD)
         const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
         // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise
         const uint32_t xl0 = __float_as_uint(R2.x), xl1 = __float_as_uint(R2.y), xh0 = __float_as_uint(R2.z), xh1 = __float_as_uint(R2.w);
@@ -1015,8 +1022,13 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         const uint32_t ny0 = ngy ? yh0 : yl0, ny1 = ngy ? yh1 : yl1, fy0 = ngy ? yl0 : yh0, fy1 = ngy ? yl1 : yh1;
         const uint32_t nz0 = ngz ? zh0 : zl0, nz1 = ngz ? zh1 : zl1, fz0 = ngz ? zl0 : zh0, fz1 = ngz ? zl1 : zh1;
         uint32_t m = 0u;
-        WF8_CHILD(7, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(6, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(5, nx1, fx1, ny1, fy1, nz1, fz1) WF8_CHILD(4, nx1, fx1, ny1, fy1, nz1, fz1)
-        WF8_CHILD(3, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(2, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(1, nx0, fx0, ny0, fy0, nz0, fz0) WF8_CHILD(0, nx0, fx0, ny0, fy0, nz0, fz0)
+        // bytes (2p, 2p + 1) of a plane word -> the fp16 pair {1024 + q, 1024 + q}
+        auto h_lo = [&](uint32_t w) __attribute__((always_inline)) { const uint32_t r = __builtin_amdgcn_perm(k64, w, 0x04010400u); wf_h2 h; __builtin_memcpy(&h, &r, 4); return h; };
+        auto h_hi = [&](uint32_t w) __attribute__((always_inline)) { const uint32_t r = __builtin_amdgcn_perm(k64, w, 0x04030402u); wf_h2 h; __builtin_memcpy(&h, &r, 4); return h; };
+        { const wf_h2 NX = h_hi(nx1), FX = h_hi(fx1), NY = h_hi(ny1), FY = h_hi(fy1), NZ = h_hi(nz1), FZ = h_hi(fz1); WF8_CHILD(7, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(6, NX, FX, NY, FY, NZ, FZ) }
+        { const wf_h2 NX = h_lo(nx1), FX = h_lo(fx1), NY = h_lo(ny1), FY = h_lo(fy1), NZ = h_lo(nz1), FZ = h_lo(fz1); WF8_CHILD(5, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(4, NX, FX, NY, FY, NZ, FZ) }
+        { const wf_h2 NX = h_hi(nx0), FX = h_hi(fx0), NY = h_hi(ny0), FY = h_hi(fy0), NZ = h_hi(nz0), FZ = h_hi(fz0); WF8_CHILD(3, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(2, NX, FX, NY, FY, NZ, FZ) }
+        { const wf_h2 NX = h_lo(nx0), FX = h_lo(fx0), NY = h_lo(ny0), FY = h_lo(fy0), NZ = h_lo(nz0), FZ = h_lo(fz0); WF8_CHILD(1, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(0, NX, FX, NY, FY, NZ, FZ) }
         const uint32_t leaf_slots = masks >> 24;                 // = p0 | p1, stored by the builder
 #ifndef WF_SCHED_STATS
         if (COUNT) n_box += (uint32_t)__popc((masks & 0xffu) | leaf_slots);
@@ -1232,6 +1244,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 }
 #undef OVF8
 #undef WF8_CHILD
+#undef WF8_H
 #undef WF8_POP
 #undef WF8_PARK
 #undef WF_TICK
