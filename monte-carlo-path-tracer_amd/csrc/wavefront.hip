@@ -914,6 +914,7 @@ typedef _Float16 wf_h2 __attribute__((ext_vector_type(2)));
             /* m = 2 m + (tn <= tf): the compare's carry shifted in by ONE add-with-carry (slot 7 first, so slot s ends up in bit s) */ \
             asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(tn), "v"(tf) : "vcc");      \
         }
+template <int N> struct WfKind { static constexpr int value = N; };
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
                                                                    int* __restrict__ stack_overflow) {
@@ -1168,17 +1169,22 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 // update as four selects: spelled with short-circuit `&&` and `if` the compiler built a branch per term and copied the hit state
                 // (tmax, triangle, u, v) at every join -- ~12 of ~64 VALU issues per triangle.  `u <= 1` of the any-hit rule is implied by
                 // v >= 0 and fl(u + v) <= 1 (rounding is monotone) and is not tested separately.
-                auto leaf_test = [&](const float4 v0, const float4 e1, const float4 e2, const int ti, const bool use) __attribute__((always_inline)) {
+                // KIND: 1 = every lane of this execution carries a closest-hit ray, 2 = every lane an any-hit ray, 0 = mixed.  A wave works through
+                // chunks of one kind (the extend rays come first in the list), so the mixed form is rare; the uniform forms drop the other rule's
+                // compares and -- any-hit -- all four selects.
+                auto leaf_test = [&](auto kind_c, const float4 v0, const float4 e1, const float4 e2, const int ti, const bool use) __attribute__((always_inline)) {
+                    constexpr int kind = decltype(kind_c)::value;
+                    const bool is_any = kind == 2 ? true : (kind == 1 ? false : any);
                     const TriTest r = tri_test(v0, e1, e2, o, d);
-                    const bool a_ok = fabsf(r.a) >= (any ? 1e-6f : 1e-5f);
-                    const bool uv_ok = (r.u >= 0.0f) & (r.v >= 0.0f) & (any ? (r.u + r.v <= 1.0f) : ((1.0f - r.u - r.v) >= 0.0f));
-                    const bool t_ok = (r.t >= 1e-4f) & (any ? (r.t <= tmax) : ((r.t < tmax) | ((r.t == tmax) & (ti < (htri & HIT_TRI_MASK)))));
+                    const bool a_ok = fabsf(r.a) >= (is_any ? 1e-6f : 1e-5f);
+                    const bool uv_ok = (r.u >= 0.0f) & (r.v >= 0.0f) & (is_any ? (r.u + r.v <= 1.0f) : ((1.0f - r.u - r.v) >= 0.0f));
+                    const bool t_ok = (r.t >= 1e-4f) & (is_any ? (r.t <= tmax) : ((r.t < tmax) | ((r.t == tmax) & (ti < (htri & HIT_TRI_MASK)))));
                     const bool acc = use & a_ok & uv_ok & t_ok;
-                    const bool upd = acc & !any;
+                    const bool upd = acc & !is_any;
                     tmax = upd ? r.t : tmax; hu = upd ? r.u : hu; hv = upd ? r.v : hv;
                     htri = upd ? (ti | __float_as_int(v0.w)) : htri;             // v0.w = lobe class << 28
-                    blocked = blocked | (acc & any);
-                    return acc & any;
+                    blocked = blocked | (acc & is_any);
+                    return acc & is_any;
                 };
                 constexpr bool one_pair = MCPT_LEAF_MAX <= 2;            // a leaf holds at most MCPT_LEAF_MAX triangles: with two the pair loop is one pass
                 uint32_t i = 0;
@@ -1196,8 +1202,14 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 #ifndef WF_SCHED_STATS
                     if (COUNT) n_tri += (use_a ? 1u : 0u) + (use_b ? 1u : 0u);
 #endif
-                    done = leaf_test(v0a, e1a, e2a, ta, use_a);
-                    if (__ballot(use_b) != 0) done = done | leaf_test(v0b, e1b, e2b, tb, use_b & !done);
+                    const uint64_t m_kind = __ballot(any), m_here = __ballot(true);
+                    if (m_kind == m_here) {
+                        done = leaf_test(WfKind<2>{}, v0a, e1a, e2a, ta, use_a);
+                        if (__ballot(use_b) != 0) done = done | leaf_test(WfKind<2>{}, v0b, e1b, e2b, tb, use_b & !done);
+                    } else {
+                        done = leaf_test(WfKind<0>{}, v0a, e1a, e2a, ta, use_a);
+                        if (__ballot(use_b) != 0) done = done | leaf_test(WfKind<0>{}, v0b, e1b, e2b, tb, use_b & !done);
+                    }
                     i += 2;
                 } while (!one_pair && i < cnt && !done);
                 if (done) { cur_y = 0u; t_y = 0u; }                      // any-hit: stop at the first occluder
