@@ -623,17 +623,17 @@ __global__ void c8_emit_kernel(const float4* __restrict__ n2, const unsigned cha
         }
     }
     int ebits[3]; double scale[3];
-    for (int a = 0; a < 3; a++) {                                   // the frame: exactly as build_bvh8 (scene_build.cpp) forms it, margin included
+    for (int a = 0; a < 3; a++) {                                   // the frame: exactly as build_bvh8 (scene_build.cpp) forms it -- stored origin 1024 + 2 margins steps below the lowest bound
         const double ext = (double)hi[a] - (double)lo[a];
         int e = ext > 0 ? (int)ceil(log2(ext / 255.0)) : -100;
         e = e < -126 ? -126 : (e > 127 ? 127 : e);
-        float lof = lo[a];
+        float org = lo[a];
         for (;; e++) {
-            const double sc = ldexp(1.0, e), lf = (double)lo[a] - 2.0 * MCPT_Q_MARGIN * sc;
-            lof = (float)lf; if ((double)lof > lf) lof = nextafterf(lof, -INFINITY);
-            if (!(ext > 0) || e >= 127 || (double)hi[a] - (double)lof + 2.0 * MCPT_Q_MARGIN * sc <= 255.0 * sc) break;
+            const double sc = ldexp(1.0, e), of = (double)lo[a] - (1024.0 + 2.0 * MCPT_Q_MARGIN) * sc;
+            org = (float)of; if ((double)org > of) org = nextafterf(org, -INFINITY);
+            if (!(ext > 0) || e >= 127 || ((double)hi[a] - (double)org) / sc - 1024.0 + MCPT_Q_MARGIN <= 255.0) break;
         }
-        lo[a] = lof; ebits[a] = e; scale[a] = ldexp(1.0, e);
+        lo[a] = org; ebits[a] = e; scale[a] = ldexp(1.0, e);
     }
     uint32_t q[3][2][2];
     for (int a = 0; a < 3; a++) { q[a][0][0] = q[a][0][1] = 0xffffffffu; q[a][1][0] = q[a][1][1] = 0u; }
@@ -642,10 +642,8 @@ __global__ void c8_emit_kernel(const float4* __restrict__ n2, const unsigned cha
     for (int sl = 0; sl < 8; sl++) {
         const int k = kid_in[sl]; if (k < 0) continue;
         for (int a = 0; a < 3; a++) {
-            double ql = floor(((double)kids[k].lo[a] - (double)lo[a]) / scale[a] - MCPT_Q_MARGIN);
-            double qh = ceil(((double)kids[k].hi[a] - (double)lo[a]) / scale[a] + MCPT_Q_MARGIN);
-            while (ql > 0 && (float)((double)lo[a] + ql * scale[a]) > kids[k].lo[a]) ql -= 1;
-            while (qh < 255 && (float)((double)lo[a] + qh * scale[a]) < kids[k].hi[a]) qh += 1;
+            double ql = floor(((double)kids[k].lo[a] - (double)lo[a]) / scale[a] - 1024.0 - MCPT_Q_MARGIN);
+            double qh = ceil(((double)kids[k].hi[a] - (double)lo[a]) / scale[a] - 1024.0 + MCPT_Q_MARGIN);
             ql = fmin(255.0, fmax(0.0, ql)); qh = fmin(255.0, fmax(0.0, qh));
             const int h = sl >> 2, sh = 8 * (sl & 3);
             q[a][0][h] = (q[a][0][h] & ~(0xffu << sh)) | ((uint32_t)ql << sh);

@@ -407,21 +407,23 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
                 ck[bk] = cs[bs] = true; kid_in[bs] = bk;
             }
         }
-        // The frame: a power-of-two step and an origin a little BELOW the lowest child bound, so that every quantised plane -- also those of
-        // children that touch the node's faces -- lies at least MCPT_Q_MARGIN steps outside its box: the trace kernel forms its plane
-        // distances as (1024 + q) a + (b - 1024 a), whose offset carries a rounding of up to 6e-5 steps (wavefront.hip, WF8_CHILD).
+        // The frame: a power-of-two step and a STORED origin 1024 + 2 margins steps below the lowest child bound.  The trace kernel forms a
+        // plane's distance as (1024 + q) a + c with q riding in the low mantissa byte of the fp16 value 1024 + q (wavefront.hip, WF8_CHILD), so
+        // plane q lies at origin + (1024 + q) step; c carries a rounding of up to 6e-5 steps, and every quantised plane -- also those of children
+        // that touch the node's faces -- is kept at least MCPT_Q_MARGIN steps outside its box.  The origin is rounded to fp32 FIRST and the
+        // planes are quantised against the rounded value: its rounding costs nothing.
         int ebits[3]; double scale[3];
         for (int a = 0; a < 3; a++) {
             const double ext = double(hi[a]) - double(lo[a]);
             int e = ext > 0 ? int(std::ceil(std::log2(ext / 255.0))) : -100;
             e = std::max(-126, std::min(127, e));
-            float lof = lo[a];
+            float org = lo[a];
             for (;; e++) {
-                const double sc = std::ldexp(1.0, e), lf = double(lo[a]) - 2.0 * MCPT_Q_MARGIN * sc;
-                lof = float(lf); if (double(lof) > lf) lof = std::nextafterf(lof, -INFINITY);
-                if (!(ext > 0) || e >= 127 || double(hi[a]) - double(lof) + 2.0 * MCPT_Q_MARGIN * sc <= 255.0 * sc) break;
+                const double sc = std::ldexp(1.0, e), of = double(lo[a]) - (1024.0 + 2.0 * MCPT_Q_MARGIN) * sc;
+                org = float(of); if (double(org) > of) org = std::nextafterf(org, -INFINITY);
+                if (!(ext > 0) || e >= 127 || (double(hi[a]) - double(org)) / sc - 1024.0 + MCPT_Q_MARGIN <= 255.0) break;
             }
-            lo[a] = lof; ebits[a] = e; scale[a] = std::ldexp(1.0, e);
+            lo[a] = org; ebits[a] = e; scale[a] = std::ldexp(1.0, e);
         }
         // empty slots keep an inverted box (lo 255, hi 0): no ray interval survives it
         uint32_t q[3][2][2];                                                         // [axis][lo / hi][slots 0-3 / 4-7]
@@ -431,10 +433,8 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
         for (int sl = 0; sl < 8; sl++) {
             const int k = kid_in[sl]; if (k < 0) continue;
             for (int a = 0; a < 3; a++) {
-                double ql = std::floor((double(kids[k].box.lo[a]) - double(lo[a])) / scale[a] - MCPT_Q_MARGIN);
-                double qh = std::ceil((double(kids[k].box.hi[a]) - double(lo[a])) / scale[a] + MCPT_Q_MARGIN);
-                while (ql > 0 && float(double(lo[a]) + ql * scale[a]) > kids[k].box.lo[a]) ql -= 1;      // the fp32 reconstruction must still enclose the child box
-                while (qh < 255 && float(double(lo[a]) + qh * scale[a]) < kids[k].box.hi[a]) qh += 1;
+                double ql = std::floor((double(kids[k].box.lo[a]) - double(lo[a])) / scale[a] - 1024.0 - MCPT_Q_MARGIN);      // (lo[] holds the stored origin now)
+                double qh = std::ceil((double(kids[k].box.hi[a]) - double(lo[a])) / scale[a] - 1024.0 + MCPT_Q_MARGIN);
                 ql = std::min(255.0, std::max(0.0, ql)); qh = std::min(255.0, std::max(0.0, qh));
                 const int h = sl >> 2, sh = 8 * (sl & 3);
                 q[a][0][h] = (q[a][0][h] & ~(0xffu << sh)) | (uint32_t(ql) << sh);
@@ -563,7 +563,7 @@ std::string validate_bvh8(const HostScene& hs) {
                 const uint32_t wl = as_u32(sl < 4 ? Q[a].x : Q[a].y), wh = as_u32(sl < 4 ? Q[a].z : Q[a].w);
                 const float qlo = float((wl >> sh) & 0xffu), qhi = float((wh >> sh) & 0xffu);
                 if (qlo > qhi) inverted = true;
-                const float lo = org[a] + qlo * sc[a], hi = org[a] + qhi * sc[a];
+                const float lo = org[a] + (1024.0f + qlo) * sc[a], hi = org[a] + (1024.0f + qhi) * sc[a];      // plane q = stored origin + (1024 + q) steps
                 ch.lo[a] = std::max(it.lo[a], lo); ch.hi[a] = std::min(it.hi[a], hi);
                 own_lo[a] = lo; own_hi[a] = hi;
             }

@@ -900,8 +900,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 #endif
 // One child box.  The six plane bytes reach the fma as the low bytes of fp16 values 1024 + q (0x64qq: one v_perm_b32 makes two of them) and
 // v_fma_mix_f32 converts on the way in -- a perm per two planes + one fma per plane instead of a v_cvt_f32_ubyte + an fma per plane
-// (-3 of 16 VALU issues per child).  The 1024 is folded into the plane offset: t = (1024 + q) a + (b - 1024 a); that offset's rounding
-// (<= 2^-24 x 1024 a = 6e-5 quantisation steps) is covered by the builder, which keeps every quantised plane >= 1e-3 steps outside the box.
+// (-3 of 16 VALU issues per child).  The 1024 lives in the STORED frame origin (the builders subtract 1024 steps and quantise against the
+// rounded result): t = (1024 + q) a + (R0 - o) / d; the offset's rounding (<= 2^-24 x 1024 a = 6e-5 quantisation steps more than a
+// plain q a + b would carry) is covered by the builders, which keep every quantised plane >= MCPT_Q_MARGIN = 2^-10 steps outside its box.
 typedef _Float16 wf_h2 __attribute__((ext_vector_type(2)));
 #define WF8_H(V, K) ((float)(V)[(K) & 1])
 #define WF8_CHILD(K, NX, FX, NY, FY, NZ, FZ)                                                                                         \
@@ -1012,8 +1013,8 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     };
     auto inner_consume = [&]() __attribute__((always_inline)) {
         const uint32_t sxy = __float_as_uint(R0.w), masks = __float_as_uint(R1.w);
-        const float ax = __uint_as_float(sxy & 0xffff0000u) * idx, ay = __uint_as_float(sxy << 16) * idy, az = __uint_as_float(__float_as_uint(R1.z) & 0xffff0000u) * idz;
-        const float bx = fmaf(-1024.0f, ax, fmaf(R0.x, idx, nox)), by = fmaf(-1024.0f, ay, fmaf(R0.y, idy, noy)), bz = fmaf(-1024.0f, az, fmaf(R0.z, idz, noz));   // (plane offset - 1024 a: see WF8_CHILD)
+        const float ax = __uint_as_float(sxy & 0xffff0000u) * idx, ay = __uint_as_float(sxy << 16) * idy, az = R1.z * idz;   // (R1.z: the builders leave its low half zero)
+        const float bx = fmaf(R0.x, idx, nox), by = fmaf(R0.y, idy, noy), bz = fmaf(R0.z, idz, noz);   // R0.xyz = the frame origin LESS 1024 steps: plane q lies at R0 + (1024 + q) step (WF8_CHILD)
         const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
         // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise
         const uint32_t xl0 = __float_as_uint(R2.x), xl1 = __float_as_uint(R2.y), xh0 = __float_as_uint(R2.z), xh1 = __float_as_uint(R2.w);
