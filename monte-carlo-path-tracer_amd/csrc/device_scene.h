@@ -26,7 +26,9 @@
 
 // 8-wide tree: every quantised child plane lies at least this many quantisation steps outside the child's box (build_bvh8,
 // gpu_collapse_bvh8) -- the margin the trace kernel's fp16-mix plane arithmetic needs (wavefront.hip, WF8_CHILD)
+#ifndef MCPT_Q_MARGIN
 #define MCPT_Q_MARGIN (1.0 / 1024.0)
+#endif
 #ifndef MCPT_LEAF_MAX
 #define MCPT_LEAF_MAX 2
 #endif
