@@ -24,7 +24,7 @@ struct PathPool {
     float4* L;          // radiance of the current path so far xyz | w: pdf of the BSDF sample that produced the extend ray
     float4* beta;       // path throughput xyz | w: uint bits  state(2) | prev_mirror(1) | shadow ray pending(1) | bounce << 8
     float4* sum;        // item accumulator: sum of finished samples xyz | w: number of finished samples
-    uint4* ids;         // pixel, current sample index, next sample index, end sample index
+    uint4* ids;         // 16 B per slot, used as two arrays of 8 B: [P x {pixel, current sample index}] [P x {next sample index, end sample index}]
     uint32_t* shadow_queue;   // slots with a pending shadow ray: shade block b owns entries [256 b, 256 b + shadow_count[b]) -- no atomics
     uint32_t* shadow_count;   // entries each shade block wrote this iteration
     uint2* block_items;       // per shade block: {next, end} of its private work-item range (RenderParams::priv_items); the block alone reads and writes it

@@ -39,6 +39,9 @@ __device__ __forceinline__ void st_s(double4* p, double4 v) {
     wf_v2d a, b; a.x = v.x; a.y = v.y; b.x = v.z; b.y = v.w;
     __builtin_nontemporal_store(a, reinterpret_cast<wf_v2d*>(p)); __builtin_nontemporal_store(b, reinterpret_cast<wf_v2d*>(p) + 1);
 }
+typedef unsigned int wf_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 ld_s(const uint2* p) { const wf_v2u v = __builtin_nontemporal_load(reinterpret_cast<const wf_v2u*>(p)); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void st_s(uint2* p, uint2 v) { wf_v2u t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<wf_v2u*>(p)); }
 __device__ __forceinline__ uint32_t ld_s(const uint32_t* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_s(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 #else
@@ -108,7 +111,9 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     // the whole slot state of the block's 256-slot window, fetched coalesced in ONE batch by the slots' own lanes and handed to the
     // lanes that will process them through LDS: no dependent second round of (gathering) global loads after the sort ...
     __shared__ float4 s_beta[WF_SHADE_BLOCK], s_hit[WF_SHADE_BLOCK], s_L[WF_SHADE_BLOCK], s_rd[WF_SHADE_BLOCK], s_nee[WF_SHADE_BLOCK], s_ro[WF_SHADE_BLOCK];
-    __shared__ uint4 s_ids[WF_SHADE_BLOCK];
+    __shared__ uint2 s_ids[WF_SHADE_BLOCK];                                        // pixel, sample index: the half of the ids record every iteration needs
+    uint2* const id_ps = reinterpret_cast<uint2*>(pool.ids);                       // pool.ids = [P x {pixel, sample}] [P x {next sample, end sample}]: the second half
+    uint2* const id_ne = id_ps + pool.P;                                           // is touched by multi-sample items only (one-sample items are exhausted by definition)
     // ... and the way back: the processing lane leaves the slot's new records in LDS (each output record reuses the LDS cell of an
     // input record of the SAME slot, which only this lane read: no hazard), and after one barrier the slots' own lanes store them
     // coalesced.  Permuted lanes storing straight to the pool write partial 128-B lines from several waves: measured 1.5x (class
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     // ---- classification of the lane's OWN slot (coalesced): which branch will this slot take?
     {
         const float4 bt0 = ld_s(&pool.beta[base + tid]), h0 = ld_s(&pool.hit[base + tid]);
-        const uint4 id0 = ld_s(&pool.ids[base + tid]);
+        const uint2 id0 = ld_s(&id_ps[base + tid]);
         const float4 L0 = ld_s(&pool.L[base + tid]), rd0 = ld_s(&pool.ray_d[base + tid]), nee0 = ld_s(&pool.nee[base + tid]), ro0 = ld_s(&pool.ray_o[base + tid]);
         // the block's private work-item range: its cursor rides in this batch of loads too (thread 0) and waits in LDS until the item pull
         uint2 priv = make_uint2(0u, 0u);
@@ -274,7 +279,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         // rounding, which no statistic sees (r01 carried a 32-B fp64 origin per slot for this: 64 B of pool traffic per bounce).
         LightSample ls; f3 p32; float xi_lobe;
         {
-            const uint4 id = s_ids[src];
+            const uint2 id = s_ids[src];
             const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
             xi_lobe = ra.v[3];
             const d3 p64 = hit_point64_plane(sc, tri, to_d3(xyz(s_ro[src])), xyz(s_rd[src]));
@@ -318,7 +323,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         s_ro[src] = mk4(p32, __int_as_float(sh_skip)); out_flags |= OUT_RAY_O;                  // both new rays start at the hit point
         Scatter s;
         {
-            const uint4 id = s_ids[src];
+            const uint2 id = s_ids[src];
             const Rng4 rb = rng_block(id.x, id.y, 2u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
             s = bsdf_sample(bsdf, xi_lobe, rb.v[0], rb.v[1]);                                   // Render.cpp:133-134
         }
@@ -340,7 +345,10 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     else if (state != SLOT_DEAD) terminated = true;                                             // miss (Render.cpp:118-119,144-145) or DRAIN
     WF_PHASE();
     SH_TICK(3)                                                                                    // phase 3: BSDF, NEE, BSDF sample
-    uint4 id = s_ids[src];                                                                      // pixel, sample, s_next, s_end
+    uint4 id;                                                                                   // pixel, sample, s_next, s_end
+    { const uint2 ps = s_ids[src]; id.x = ps.x; id.y = ps.y; id.z = id.w = 0u; }
+    const bool multi = p.samples_per_item != 1u && p.probe_n == 0u;                             // (a probe item is one sample)
+    if (multi && (terminated || state == SLOT_DEAD)) { const uint2 ne = ld_s(&id_ne[slot]); id.z = ne.x; id.w = ne.y; }   // fetched only when a path ends, like `sum`
 
     // one-sample items (the default) flush every finished sample straight to the film: their accumulator record is always zero, so
     // it is neither fetched (a dependent round trip in front of the regeneration) nor written back
@@ -451,7 +459,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         b4.w = __uint_as_float(state | (prev_mirror ? 4u : 0u) | (emit_shadow ? 8u : 0u) | ((uint32_t)bounce << 8));
         s_beta[src] = b4;
         if (sum_dirty && sm_loaded) st_s(&pool.sum[slot], sm);                   // multi-sample items only (not the default): stored directly
-        if (id_dirty) { s_ids[src] = id; out_flags |= OUT_IDS; }
+        if (id_dirty) { s_ids[src] = make_uint2(id.x, id.y); out_flags |= OUT_IDS; if (multi) st_s(&id_ne[slot], make_uint2(id.z, id.w)); }
         float4 r4 = s_rd[src];
         r4.w = __uint_as_float(out_flags | (emit_extend ? 1u : 0u));
         s_rd[src] = r4;
@@ -480,7 +488,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         st_s(&pool.beta[own], s_beta[tid]); st_s(&pool.L[own], s_L[tid]); st_s(&pool.ray_d[own], rdo);
         if (fl & OUT_RAY_O) st_s(&pool.ray_o[own], s_ro[tid]);
         if (fl & OUT_SHADOW) st_s(&pool.nee[own], s_nee[tid]);
-        if (fl & OUT_IDS) st_s(&pool.ids[own], s_ids[tid]);
+        if (fl & OUT_IDS) st_s(&id_ps[own], s_ids[tid]);
     }
     SH_TICK(5)                                                                                    // shadow-queue append + coalesced stores
     // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
