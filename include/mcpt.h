@@ -82,6 +82,12 @@ typedef struct mcpt_scene_desc {
                                                instead of the host's binned-SAH builder: ~2x faster construction, within ~5 % of the host
                                                tree's render speed; rendered results are the same (closest hit does not depend on the tree) */
 
+#define MCPT_FLAG_REFERENCE_TIE_ORDER 0x10u /* among triangles hit at EXACTLY the same distance the one that comes first in the reference's own
+                                               BVH::triangles order wins (BVH.cpp:15-54 + :95-113: left, right, own triangles; `t < t2` strict) --
+                                               mcpt_create then replays the reference's midpoint partition to learn that order (O(n log n) on the
+                                               host).  Default: the lowest index in this library's leaf order wins (any fixed rule gives the same
+                                               image up to measure-zero ties; this flag is for tie-break-exact known-answer tests) */
+
 typedef struct mcpt_opts {
     uint32_t struct_size;       /* = sizeof(mcpt_opts) */
     int32_t  device;            /* HIP device ordinal */

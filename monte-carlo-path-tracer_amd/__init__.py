@@ -28,6 +28,7 @@ FLAG_CORRECT_SHADOW_T2 = 0x1
 FLAG_DETERMINISTIC = 0x2
 FLAG_COUNT_TRAVERSAL = 0x4
 FLAG_GPU_BVH_BUILD = 0x8
+FLAG_REFERENCE_TIE_ORDER = 0x10
 
 
 class Texture(C.Structure):

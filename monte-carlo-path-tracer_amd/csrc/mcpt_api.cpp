@@ -260,6 +260,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
 
     HostScene hs; std::string err;
     hs.bvh_width = env_u32("MCPT_BVH_WIDTH", 8) == 4 ? 4u : 8u;          // developer knob: 4 = the round-2 4-wide tree and its kernel
+    hs.reference_tie_order = (o.flags & MCPT_FLAG_REFERENCE_TIE_ORDER) != 0;
     // which pipeline this context runs is decided ONCE, here: it sets how deep a device-built binary tree may be (below) and which kernels
     // mcpt_render launches -- the two must agree, or a megakernel context could walk a tree deeper than its LDS stack
     const bool use_wavefront = [&]() { const char* pipe = std::getenv("MCPT_PIPELINE"); return !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS; }();

@@ -589,6 +589,41 @@ std::string validate_bvh8(const HostScene& hs) {
     return "";
 }
 
+// MCPT_FLAG_REFERENCE_TIE_ORDER: where every face ends up in the reference's BVH::triangles.  BVH::build (BVH.cpp:15-54) partitions the
+// range [l, r) about the midpoint (narrowed to float, :39) of the CENTROID box's longest axis (AABB::max_axis, AABB.cpp:12-23) with
+// std::partition -- the same libstdc++ algorithm `oracle/_ref` is built with, so the order is the same element for element -- halves the
+// range by count where that leaves a side empty (:46-48), and stops at ranges of <= 5 (BVH.h:32).  BVH_node::hit (BVH.cpp:95-113) visits
+// left, right, then the node's own triangles with a strict `t < t2`: among exact ties the triangle that comes first in this order wins.
+// Ranges are disjoint, so an explicit stack replaces the recursion (a midpoint split can be as lopsided as 1 : n - 1).
+static void reference_triangle_order(const mcpt_scene_desc* d, std::vector<uint32_t>& rank) {
+    const uint32_t nf = d->n_face;
+    std::vector<double> cen(3 * size_t(nf));
+    for (uint32_t f = 0; f < nf; f++) {
+        const int32_t* c = d->face + 12 * size_t(f);
+        const double* v0 = d->vertex + 3 * size_t(c[0]); const double* v1 = d->vertex + 3 * size_t(c[4]); const double* v2 = d->vertex + 3 * size_t(c[8]);
+        for (int a = 0; a < 3; a++) cen[3 * size_t(f) + a] = (v0[a] + v1[a] + v2[a]) / 3.0;                 // Triangle::center (Triangle.cpp:30-33)
+    }
+    std::vector<int> ord(nf);
+    for (uint32_t f = 0; f < nf; f++) ord[f] = int(f);
+    std::vector<std::pair<int, int>> todo; todo.push_back({0, int(nf)});
+    while (!todo.empty()) {
+        const int l = todo.back().first, r = todo.back().second; todo.pop_back();
+        if (r - l <= 5) continue;
+        double A[3], B[3];
+        for (int a = 0; a < 3; a++) { A[a] = std::numeric_limits<double>::max(); B[a] = std::numeric_limits<double>::lowest(); }          // AABB.h:14
+        for (int i = l; i < r; i++) for (int a = 0; a < 3; a++) { const double c = cen[3 * size_t(ord[i]) + a]; A[a] = std::min(A[a], c); B[a] = std::max(B[a], c); }
+        int axis = 0; double len = B[0] - A[0];
+        for (int a = 0; a < 3; a++) { const double t = B[a] - A[a]; if (len < t) { len = t; axis = a; } }
+        const float mid_val = float((A[axis] + B[axis]) / 2.0);
+        auto mid = std::partition(ord.begin() + l, ord.begin() + r, [&](int f) { return cen[3 * size_t(f) + axis] < mid_val; });
+        int m = int(mid - ord.begin());
+        if (m == l || m == r) m = (l + r) / 2;
+        todo.push_back({l, m}); todo.push_back({m, r});
+    }
+    rank.resize(nf);
+    for (uint32_t i = 0; i < nf; i++) rank[size_t(ord[i])] = i;
+}
+
 mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh, const Collapse4Fn& custom_collapse,
                              const Collapse8Fn& custom_collapse8) {
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
@@ -732,6 +767,8 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     for (uint32_t i = 0; i < nf; i++) pos_of_face[order[i]] = int(i);
 
     // ---- streams in leaf order
+    std::vector<uint32_t> ref_rank;
+    if (out.reference_tie_order) reference_triangle_order(d, ref_rank);
     out.tri_isect.assign(3 * size_t(nf) + 3, f4h{0.f, 0.f, 0.f, 0.f});    /* + one spare record: the trace kernel fetches triangles in pairs */ out.tri_shade.resize(4 * size_t(nf)); out.tri_pos64.resize(9 * size_t(nf)); out.tri_plane64.resize(4 * size_t(nf)); out.tri_face.resize(nf);
     parallel_for(nf, [&](uint32_t i_begin, uint32_t i_end) {
     for (uint32_t i = i_begin; i < i_end; i++) {
@@ -743,7 +780,8 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         const double* t0_ = d->texcoord + 2 * size_t(c[2]); const double* t1_ = d->texcoord + 2 * size_t(c[6]); const double* t2_ = d->texcoord + 2 * size_t(c[10]);
         const uint32_t mflags = out.mats[size_t(c[3])].flags;
         const uint32_t lobe_class = !(mflags & MAT_HAS_SPEC) ? HIT_CLASS_DIFFUSE : (mflags & MAT_MIRROR) ? HIT_CLASS_MIRROR : HIT_CLASS_PHONG;
-        out.tri_isect[3 * size_t(i) + 0] = {float(v0[0]), float(v0[1]), float(v0[2]), as_float(int(lobe_class << HIT_CLASS_SHIFT))};
+        // .w: lobe class | the triangle's TIE RANK -- among hits at exactly the same distance the lowest rank wins (tri_accept in the trace kernels)
+        out.tri_isect[3 * size_t(i) + 0] = {float(v0[0]), float(v0[1]), float(v0[2]), as_float(int((lobe_class << HIT_CLASS_SHIFT) | (out.reference_tie_order ? ref_rank[size_t(f)] : i)))};
         out.tri_isect[3 * size_t(i) + 1] = {float(w1[0] - w0[0]), float(w1[1] - w0[1]), float(w1[2] - w0[2]), 0.f};      // (edges from the world coordinates: Triangle.cpp:25-26's values)
         out.tri_isect[3 * size_t(i) + 2] = {float(w2[0] - w0[0]), float(w2[1] - w0[1]), float(w2[2] - w0[2]), 0.f};
         out.tri_shade[4 * size_t(i) + 0] = {float(n0[0]), float(n0[1]), float(n0[2]), float(t0_[0])};

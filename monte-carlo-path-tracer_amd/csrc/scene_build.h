@@ -28,6 +28,8 @@ struct HostScene {
     uint32_t bvh_depth = 0, max_leaf = 0, bvh4_depth = 0, bvh8_depth = 0;
     std::vector<int> subtree_begin;  // binary nodes: first index of every depth-first-numbered subtree below the breadth-first top levels (ascending)
     uint32_t bvh_width = 8;          // in: which wide tree the wavefront trace kernel will walk (4 = the round-2 tree, a developer knob)
+    bool reference_tie_order = false; // in: MCPT_FLAG_REFERENCE_TIE_ORDER -- the tie rank of a triangle (low 28 bits of tri_isect[3 i].w) is its position in the
+                                     //     reference's BVH::triangles after BVH::build instead of its position in this library's leaf order
     bool allow_deep_binary = false;  // in: the caller never traverses `nodes` (wavefront pipeline only) -> a device tree deeper than MCPT_STACK_DEPTH is fine
     bool binary_ok = true;           // out: `nodes` fits the binary-tree kernels' stack
     double bvh_build_ms = 0.0;

@@ -754,12 +754,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
                     if (use_a) {
                         const TriTest r = tri_test(v0a, e1a, e2a, o, d);
                         if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }                     // Triangle::isIntersect
-                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ta | __float_as_int(v0a.w); hu = r.u; hv = r.v; }   // Triangle::hit; v0.w = lobe class << 28
+                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ta | (__float_as_int(v0a.w) & ~HIT_TRI_MASK); hu = r.u; hv = r.v; }   // Triangle::hit; v0.w = lobe class << 28
                     }
                     if (use_b && !done) {
                         const TriTest r = tri_test(v0b, e1b, e2b, o, d);
                         if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }
-                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = tb | __float_as_int(v0b.w); hu = r.u; hv = r.v; }
+                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = tb | (__float_as_int(v0b.w) & ~HIT_TRI_MASK); hu = r.u; hv = r.v; }
                     }
                 }
 #ifndef WF_NO_POSTPONE
@@ -991,6 +991,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     uint32_t cur_x = 0, cur_y = 0, t_x = 0, t_y = 0, oct = 0;
     int sp = 1;
     int htri = -1; float hu = 0, hv = 0;
+    uint32_t hrank = 0;                                                // tie rank of the best hit so far (closest-hit rays)
     uint32_t n_box = 0, n_tri = 0, n_spill = 0;
 #ifdef WF_SCHED_STATS
     uint32_t x_inner = 0, x_leaf = 0, x_refill = 0, l_refill = 0;
@@ -1131,7 +1132,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                         const float4 rd = ld_s(&pool.ray_d[my_w]);
                         valid = (__float_as_uint(rd.w) & 1u) != 0u;
                         const float4 ro = ld_s(&pool.ray_o[my_w]);
-                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; htri = -1;
+                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; htri = -1; hrank = 0u;
                     } else {
                         slot = ld_s(&pool.shadow_queue[my_q + my_w]);
                         const float4 ro = ld_s(&pool.sq_o[my_q + my_w]), sd = ld_s(&pool.sq_d[my_q + my_w]);
@@ -1187,11 +1188,16 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     const TriTest r = tri_test(v0, e1, e2, o, d);
                     const bool a_ok = fabsf(r.a) >= (is_any ? 1e-6f : 1e-5f);
                     const bool uv_ok = (r.u >= 0.0f) & (r.v >= 0.0f) & (is_any ? (r.u + r.v <= 1.0f) : ((1.0f - r.u - r.v) >= 0.0f));
-                    const bool t_ok = (r.t >= 1e-4f) & (is_any ? (r.t <= tmax) : ((r.t < tmax) | ((r.t == tmax) & (ti < (htri & HIT_TRI_MASK)))));
+                    // a hit at EXACTLY the distance of the best one so far wins iff its tie rank (low 28 bits of v0.w: the triangle's place in the
+                    // leaf order, or in the reference's own triangle order -- MCPT_FLAG_REFERENCE_TIE_ORDER) is lower; hrank = the best hit's rank
+                    const uint32_t rank = __float_as_uint(v0.w) & HIT_TRI_MASK;
+                    const bool tie_win = (r.t == tmax) & (rank < hrank);
+                    const bool t_ok = (r.t >= 1e-4f) & (is_any ? (r.t <= tmax) : ((r.t < tmax) | tie_win));
                     const bool acc = use & a_ok & uv_ok & t_ok;
                     const bool upd = acc & !is_any;
                     tmax = upd ? r.t : tmax; hu = upd ? r.u : hu; hv = upd ? r.v : hv;
-                    htri = upd ? (ti | __float_as_int(v0.w)) : htri;             // v0.w = lobe class << 28
+                    htri = upd ? (ti | (__float_as_int(v0.w) & ~HIT_TRI_MASK)) : htri;   // v0.w = lobe class << 28 | tie rank
+                    hrank = upd ? rank : hrank;
                     blocked = blocked | (acc & is_any);
                     return acc & is_any;
                 };

@@ -18,7 +18,7 @@
 
 static void usage() {
     std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--shard samples|tiles] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
-                 "                          [--deterministic] [--ref-index-order] [--gpu-bvh] [--check] [--dump-model file] [--save-every K]\n"
+                 "                          [--deterministic] [--ref-index-order] [--ref-tie-order] [--gpu-bvh] [--check] [--dump-model file] [--save-every K]\n"
                  "       mcpt_cli --decode-image texture.(png|jpg|ppm) out.ppm\n";
 }
 
@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
         else if (a == "--recursive") integrator = MCPT_INTEGRATOR_RECURSIVE_NEE; else if (a == "--corrected") flags |= MCPT_FLAG_CORRECT_SHADOW_T2;
         else if (a == "--deterministic") flags |= MCPT_FLAG_DETERMINISTIC; else if (a == "--ref-index-order") ref_order = true;
         else if (a == "--gpu-bvh") flags |= MCPT_FLAG_GPU_BVH_BUILD;
+        else if (a == "--ref-tie-order") flags |= MCPT_FLAG_REFERENCE_TIE_ORDER;
         else if (a == "--check") check_only = true;
         else if (a == "--dump-model") dump_model = next();
         else if (a == "--save-every") save_every = uint32_t(std::atoi(next()));

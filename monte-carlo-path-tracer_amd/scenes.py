@@ -392,7 +392,20 @@ def open_box(width=32, height=32) -> SceneData:
     return s2
 
 
+def tie_floor(width=96, height=96) -> SceneData:
+    """S-cornell-small with EIGHT coincident copies of its floor, each in its own colour: every floor hit is an eight-way exact tie -- the
+    known-answer scene for the tie-breaking rule (the reference: the copy that comes first in its BVH::triangles order, BVH.cpp:95-113)."""
+    base = cornell_box_small(width, height)
+    floor = base.face[:2].copy()                                           # add_grid(floor) comes first: two triangles
+    cols = [(0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9), (0.9, 0.9, 0.1), (0.9, 0.1, 0.9), (0.1, 0.9, 0.9), (0.5, 0.5, 0.5), (0.2, 0.2, 0.2)]
+    mats = list(base.materials); faces = [base.face]
+    for k, c in enumerate(cols[1:]):
+        mats.append(Material("floor%d" % k, kd=c)); f = floor.copy(); f[:, :, 3] = len(mats) - 1; faces.append(f)
+    return SceneData("ties", base.vertex, base.normal, base.texcoord, np.concatenate(faces), mats, base.camera, {})
+
+
 SCENES = {
+    "tie-floor": tie_floor,
     "cornell-box": cornell_box,
     "cornell-box-small": cornell_box_small,
     "veach-mis": veach_mis,

@@ -20,6 +20,8 @@ Files:
   ref_fullsize_<c>.npz (round 3) 8x8-block mean / variance-of-the-mean maps of the real reference at the bench configurations' own sizes
                        (c2: S-cornell 800x800 depth 8; c3: S-veach 1280x720; c4s: S-bath 93 k triangles 1920x1080), 128 spp each
                        (`... make_golden.py fullsize c2` etc.: one configuration per process, tens of CPU-minutes each)
+  ref_ties.npz         (round 3) BVH::hit of the real reference on rays into eight coincident floors: which face wins an exact tie
+                       (`... make_golden.py ties`)
   ref_loader.npz       (round 2) the reference's own Model(filename) parse of tests/golden/loader_quirks/quirk.obj (this project's
                        quirk-exercising input) and of a scenes.py-written S-bath small (`... make_golden.py loader`)
 """
@@ -296,7 +298,37 @@ def loader():
     print("loader golden written:", {k: v.shape for k, v in out.items() if k.startswith("quirk_")})
 
 
+def ties():
+    """(round 3) BVH::hit of the real reference on rays that hit the eight coincident floors of scenes.tie_floor: which face wins an EXACT
+    eight-way tie is decided by the reference's own triangle order after BVH::build (BVH.cpp:15-54, :95-113) -- the known answers for
+    MCPT_FLAG_REFERENCE_TIE_ORDER."""
+    scene = pkg.scenes.tie_floor(96, 96)
+    ref = orc.Reference()
+    ref.load(scene.write(tempfile.mkdtemp(prefix="mcpt_golden_")))
+    rng = np.random.RandomState(20251005)
+    n = 4000
+    V = np.asarray(scene.vertex, np.float64); F = np.asarray(scene.face)
+    fl = F[:2, :, 0]                                                        # the floor's two triangles (vertex indices)
+    # targets: uniformly inside the floor's triangles; origins: anywhere above, inside the box
+    pick = rng.randint(0, 2, n); b = rng.rand(n, 2); flip = b.sum(1) > 1; b[flip] = 1 - b[flip]
+    tv = V[fl[pick]]                                                        # (n, 3 corners, 3)
+    target = tv[:, 0] + b[:, :1] * (tv[:, 1] - tv[:, 0]) + b[:, 1:] * (tv[:, 2] - tv[:, 0])
+    lo, hi = V.min(0), V.max(0)
+    up = np.argmax(np.abs(np.cross(tv[0, 1] - tv[0, 0], tv[0, 2] - tv[0, 0])))   # the floor's normal axis
+    origin = lo + (hi - lo) * rng.uniform(0.1, 0.9, (n, 3)); origin[:, up] = lo[up] + (hi[up] - lo[up]) * rng.uniform(0.3, 0.9, n)
+    d = unit(target - origin)
+    tri = np.zeros(n, np.int32); t = np.zeros(n)
+    for i in range(n):
+        h, out = ref.bvh_hit(origin[i], d[i]); tri[i] = int(out[11]) if h else -1; t[i] = out[0]
+    floor_faces = set(range(2)) | set(range(len(F) - 14, len(F)))
+    on_floor = np.array([int(x) in floor_faces for x in tri])
+    print("ties: %d rays, %d end on a floor copy; winners:" % (n, on_floor.sum()), dict(zip(*np.unique(tri[on_floor], return_counts=True))))
+    np.savez_compressed(os.path.join(HERE, "ref_ties.npz"), ray_o=origin, ray_d=d, tri=tri, t=t, n_face=np.int32(len(F)))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ties":
+        ties(); return
     os.environ["OMP_NUM_THREADS"] = "1"     # the reference's global mt19937 is racy across threads; single-threaded = reproducible
     if len(sys.argv) > 1 and sys.argv[1] == "scenes2":
         scenes2(); return

@@ -1101,20 +1101,34 @@ def test_exact_ties_have_a_defined_winner(pkg):
     groups in an order that depends on when its wave ran the leaf block, so it picks the lowest leaf-order index among equal distances
     (tri_accept_closest_tie) -- the winner is a function of the ray, not of the schedule: two renders of the same samples agree, however
     the samples are split over calls, and the floor has ONE colour per triangle pair (no salt-and-pepper mix of the eight)."""
-    S = pkg.scenes
-    base = S.cornell_box_small(96, 96)
-    floor = base.face[:2].copy()                                           # add_grid(floor) comes first: two triangles
-    cols = [(0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9), (0.9, 0.9, 0.1), (0.9, 0.1, 0.9), (0.1, 0.9, 0.9), (0.5, 0.5, 0.5), (0.2, 0.2, 0.2)]
-    mats = list(base.materials); faces = [base.face]
-    for k, c in enumerate(cols[1:]):
-        mats.append(S.Material("floor%d" % k, kd=c)); f = floor.copy(); f[:, :, 3] = len(mats) - 1; faces.append(f)
-    scene = S.SceneData("ties", base.vertex, base.normal, base.texcoord, np.concatenate(faces), mats, base.camera, {})
+    scene = pkg.scenes.tie_floor(96, 96)
     r = pkg.Renderer(scene, max_depth=4, flags=pkg.FLAG_CORRECT_SHADOW_T2)
     r.render(16, seed=5); a = r.read_accum()
     r.clear(); r.render(8, seed=5, first_sample=0); r.render(8, seed=5, first_sample=8); b = r.read_accum()
     r.clear(); r.render(16, seed=5); c = r.read_accum(); r.close()
     assert np.all(a[..., 3] == 16) and np.isfinite(a).all()
     assert np.allclose(a, b, rtol=1e-4, atol=1e-4) and np.allclose(a, c, rtol=1e-4, atol=1e-4)
+
+
+def test_exact_ties_follow_the_reference_order_when_asked(pkg):
+    """MCPT_FLAG_REFERENCE_TIE_ORDER: the production trace kernel names the SAME face as the real reference's BVH::hit on every ray into the
+    eight coincident floors (tests/golden/ref_ties.npz, generated by make_golden.py from oracle/_ref) -- the winner of an exact tie is the
+    copy that comes first in the reference's own BVH::triangles order (BVH.cpp:15-54, :95-113), whatever tree this library built.  Without
+    the flag the rule is this library's own (lowest leaf-order index): still ONE winner per floor triangle, generally another copy."""
+    with np.load(os.path.join(G, "ref_ties.npz")) as z:
+        o, d, tri, t, nf = z["ray_o"], z["ray_d"], z["tri"], z["t"], int(z["n_face"])
+    scene = pkg.scenes.tie_floor(96, 96)
+    assert len(scene.face) == nf
+    floor = np.isin(tri, np.r_[0:2, nf - 14:nf])
+    assert floor.sum() > 1000
+    for fl in (0, pkg.FLAG_GPU_BVH_BUILD):
+        r = pkg.Renderer(scene, max_depth=4, flags=pkg.FLAG_REFERENCE_TIE_ORDER | fl)
+        t4, tri4, _, _ = r.probe_trace4(o, d); r.close()
+        assert np.array_equal(tri4[floor], tri[floor])                                   # exact ties: the reference's winner, ray by ray
+        assert (tri4 == tri).mean() >= 0.999 and np.allclose(t4[tri4 == tri], t[tri4 == tri], rtol=2e-5, atol=2e-6)
+    r = pkg.Renderer(scene, max_depth=4); _, own, _, _ = r.probe_trace4(o, d); r.close()
+    first_tri = np.isin(own[floor], np.r_[0, nf - 14:nf:2])                                # copies of the floor's first / second triangle
+    assert len(set(own[floor][first_tri])) == 1 and len(set(own[floor][~first_tri])) == 1 and np.isin(own[floor], np.r_[0:2, nf - 14:nf]).all()
 
 
 # ------------------------------------------------------------------------------------------------ the bench configurations themselves
