@@ -442,6 +442,13 @@ DEV d3 hit_point64_plane(const DevScene& sc, int tri, d3 o64, f3 dir) {
     const double t = (nd0 - dot(n, o64)) * rcp64(dot(n, dd));
     return mkd(fma(t, dd.x, o64.x), fma(t, dd.y, o64.y), fma(t, dd.z, o64.z));
 }
+// the same with the plane record fetched by the caller (the shade kernel requests it a phase early, beside the hit's shading record)
+DEV d3 hit_point64_plane(const double4 pl, d3 o64, f3 dir) {
+    const d3 n = mkd(pl.x, pl.y, pl.z);
+    const d3 dd = to_d3(dir);
+    const double t = (pl.w - dot(n, o64)) * rcp64(dot(n, dd));
+    return mkd(fma(t, dd.x, o64.x), fma(t, dd.y, o64.y), fma(t, dd.z, o64.z));
+}
 DEV LightSample sample_light(const DevScene& sc, d3 p64, float xi_l, float xi_u, float xi_v, bool guard) {
     return sample_light(light_fetch(sc, xi_l), p64, xi_u, xi_v, guard, mkd(sc.centre[0], sc.centre[1], sc.centre[2]));
 }

@@ -235,9 +235,11 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     }
     if (key != K_END) do {                                                             // ALIVE and the extend ray hit something
         int tri;
+        double4 plane64;                                                               // the hit triangle's fp64 plane: requested here, beside the shading record,
         {   // ---- phase 1: the hit record (Triangle.cpp:68-76), emitter MIS (Render.cpp:146-162), roulette rescale, first-hit emission
             const float4 h = s_hit[src];
             tri = __float_as_int(h.x) & HIT_TRI_MASK;
+            plane64 = reinterpret_cast<const double4*>(sc.tri_plane64)[tri];            // used a phase later: one dependent gather less in front of the light sample
             const f3 d = xyz(s_rd[src]);
             const HitShade hs = load_hit_shade(sc, tri, h.y, h.z, d);                            // h.y, h.z: fp32 barycentrics of the traversal
             const float4 m1 = mats_lds ? s_mats[4 * hs.mat + 1] : reinterpret_cast<const float4*>(sc.mats)[4 * hs.mat + 1];   // radiance | flags
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
             const uint2 id = s_ids[src];
             const Rng4 ra = rng_block(id.x, id.y, 1u + 2u * (uint32_t)bounce, p.seed_lo, p.seed_hi);
             xi_lobe = ra.v[3];
-            const d3 p64 = hit_point64_plane(sc, tri, to_d3(xyz(s_ro[src])), xyz(s_rd[src]));
+            const d3 p64 = hit_point64_plane(plane64, to_d3(xyz(s_ro[src])), xyz(s_rd[src]));
             p32 = to_f3(p64);
             LightData ld;
             if (lights_lds) {
