@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     if (key != K_END) do {                                                             // ALIVE and the extend ray hit something
         int tri;
         double4 plane64;                                                               // the hit triangle's fp64 plane: requested here, beside the shading record,
+        f3 kd_early = mk3(0.f, 0.f, 0.f);
         {   // ---- phase 1: the hit record (Triangle.cpp:68-76), emitter MIS (Render.cpp:146-162), roulette rescale, first-hit emission
             const float4 h = s_hit[src];
             tri = __float_as_int(h.x) & HIT_TRI_MASK;
@@ -271,6 +272,13 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
             if (bounce == 0 && (mflags & MAT_EMIT_0)) { float4 L4 = s_L[src]; L4.x += m1.x; L4.y += m1.y; L4.z += m1.z; s_L[src] = L4; }   // :121-122
             // park what the BSDF phase needs of the hit record in the two cells this slot no longer needs (hit, NEE payload)
             s_hit[src] = mk4(hs.n, hs.tu); s_nee[src] = make_float4(hs.tv, __int_as_float(hs.mat), 0.f, 0.f);
+            {   // the diffuse colour's texel is requested here and used two phases later (three registers across the light sample: S-bath
+                // -0.4 ... -1 % of the step; nothing to fetch for a constant-colour material)
+                DevMaterial mat;
+                if (mats_lds) { float4* m4 = reinterpret_cast<float4*>(&mat); m4[0] = s_mats[4 * hs.mat]; m4[1] = s_mats[4 * hs.mat + 1]; m4[2] = s_mats[4 * hs.mat + 2]; m4[3] = s_mats[4 * hs.mat + 3]; }
+                else mat = sc.mats[hs.mat];
+                kd_early = tex_color(sc, mat, hs.tu, hs.tv, c_texel);
+            }
         }
         WF_PHASE();
         SH_TICK(1)                                                                                // phase 1: hit record gather, emitter MIS
@@ -306,7 +314,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
             DevMaterial mat;
             if (mats_lds) { float4* m4 = reinterpret_cast<float4*>(&mat); m4[0] = s_mats[4 * mi]; m4[1] = s_mats[4 * mi + 1]; m4[2] = s_mats[4 * mi + 2]; m4[3] = s_mats[4 * mi + 3]; }
             else mat = sc.mats[mi];
-            const f3 kd = tex_color(sc, mat, hn.w, ht.x, c_texel);
+            const f3 kd = kd_early;                                                             // (Texture::get_color: fetched in phase 1)
             bsdf = make_bsdf(mat, kd, xyz(hn), -xyz(s_rd[src]));
         }
         int sh_skip = -1;
