@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <random>
 #include <string>
@@ -68,10 +69,20 @@ int main(int argc, char** argv) {
         d.camera = {{0, 0, 5}, {0, 0, 0}, {0, 1, 0}, 40.0, 64, 48};
         if (kind == 2 && pick(5) == 0) d.camera.width = pick(2) ? 0 : -1;
         HostScene hs; std::string err;
+        hs.reference_tie_order = (c % 3) == 0;                 // MCPT_FLAG_REFERENCE_TIE_ORDER: the reference's std::partition order replayed on hostile input too
         const mcpt_status st = build_host_scene(&d, hs, err);
         if (st != MCPT_OK) { rejected++; continue; }
         accepted++;
-        const std::string why = validate_wide_bvh(hs);
+        std::string why = validate_wide_bvh(hs);
+        if (why.empty()) {                                     // the tie ranks (low 28 bits of every intersection record's .w) are a permutation of 0 .. n-1
+            const size_t nt = hs.tri_face.size();
+            std::vector<uint8_t> seen(nt, 0);
+            for (size_t i = 0; i < nt && why.empty(); i++) {
+                uint32_t w; std::memcpy(&w, &hs.tri_isect[3 * i].w, 4); w &= 0x0fffffffu;
+                if (w >= nt || seen[w]++) why = "tie ranks are not a permutation";
+                else if (!hs.reference_tie_order && w != i) why = "default tie rank is not the leaf-order index";
+            }
+        }
         if (!why.empty()) { unsound++; std::printf("case %d kind %d: accepted but tree unsound: %s\n", c, kind, why.c_str()); }
     }
     std::printf("%d cases: %d accepted, %d rejected, %d unsound\n", cases, accepted, rejected, unsound);
