@@ -10,12 +10,13 @@
 //                    hit of the slot's extend ray (emitter MIS, Russian roulette, termination, film write, regeneration of the next camera
 //                    ray) and produces the next extend ray + at most one shadow ray (atomic-free queue of complete ray records: block b
 //                    owns entries [256 b, 256 b + n)); the slots' own lanes then store the changed records coalesced.  ~100 VGPRs.
-//   wf_trace_kernel  persistent waves over the ray list [P extend slots | per-block shadow queues]; closest-hit and any-hit
-//                    rays share one traversal loop over the 4-wide quantised tree.  Each wave schedules itself with
-//                    __ballot/__popcll: it runs the inner-node block while most lanes sit at inner nodes, the leaf block
-//                    once enough lanes cannot go on without their (parked) leaf, and the refill block (write results back, pull fresh
-//                    rays from a wave-private chunk of the list) once enough lanes are idle -- so the expensive blocks execute with
-//                    well-packed lanes.  71 VGPRs; 1024-thread blocks with 64 KB of LDS (top tree levels + per-lane stack).
+//   wf_trace8_kernel persistent waves over the ray list [P extend slots | per-block shadow queues]; closest-hit and any-hit rays share
+//                    one traversal loop over the 8-wide compressed tree (80-B nodes, octant-ordered children, group stack entries).  Each
+//                    wave schedules itself with __ballot/__popcll: it runs the inner-node block while most lanes sit at inner nodes, the
+//                    leaf block once enough lanes cannot go on without their (parked) leaf, and the refill block (write results back, pull
+//                    fresh rays from a wave-private chunk of the list) once enough lanes are idle -- so the expensive blocks execute with
+//                    well-packed lanes.  71 VGPRs; 1024-thread blocks with 63 KB of LDS (top tree levels + per-lane stack).
+//   wf_trace_kernel  the round-2 kernel over the 4-wide quantised tree, kept behind MCPT_BVH_WIDTH=4 (developer knob, A/B baseline).
 // DESIGN.md §5 has the measurements behind each of these choices.
 #include "pt_device.h"
 #include "wavefront.h"
