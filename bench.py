@@ -304,7 +304,7 @@ def main():
     if rank == 0:
         # ---- kernel durations: the library brackets the launches of every MCPT_TIME_KERNELS-th iteration of the timed region with HIP
         # events recorded on the launch stream (a sub-pipeline stream forked from `side`); *_ms_total = sampled mean x launches
-        # since reset_counters().  Dominant kernel = wf_trace_kernel (BVH traversal); one launch of it per pipeline iteration.
+        # since reset_counters().  Dominant kernel = wf_trace8_kernel (BVH traversal); one launch of it per pipeline iteration.
         launches = max(1, c.iterations)
         trace_ms = c.trace_ms_total / launches
         shade_ms = c.shade_ms_total / launches

@@ -126,7 +126,7 @@ typedef struct mcpt_scene_info {
     uint32_t width, height;
     uint64_t device_bytes;      /* HBM held by the scene (nodes + triangle streams + textures + accumulator + path pools allocated so far) */
     double   bvh_build_ms, upload_ms;
-    /* ABI 3: the wide tree the wavefront trace kernel walks (8 children per node unless a developer knob asked for the 4-wide one) */
+    /* ABI 3: the wide tree the wavefront trace kernel walks (8 children per node; wide_width is always 8 since round 4, when the round-2 4-wide kernel was removed) */
     uint32_t wide_width, wide_nodes, wide_depth, reserved0;
     uint64_t traversal_bytes;   /* wide nodes + triangle intersection records: what a ray's traversal can touch */
     double   centre[3];         /* device coordinates are relative to this point (the fp64 centre of the scene's bounding box) */
@@ -199,8 +199,8 @@ mcpt_status mcpt_set_null_stream(mcpt_ctx* ctx);
 mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir,
                              const double* t1, const double* t2, int any_hit,
                              float* out_t, int32_t* out_tri, float* out_u, float* out_v);
-/* The same two reference functions through the PRODUCTION traversal kernel (wf_trace_kernel over the 4-wide quantised tree:
- * LDS top levels, LDS + global overflow stack, chunked ray list): the rays are placed in a path pool the way the shade kernel
+/* The same two reference functions through the PRODUCTION traversal kernel (wf_trace8_kernel over the 8-wide compressed tree:
+ * LDS top levels, LDS + global overflow group stack, chunked ray list): the rays are placed in a path pool the way the shade kernel
  * leaves them, the trace kernel runs once, results come back from the pool.  t1 is the kernel's fixed 1e-4 (Render.h:30);
  * closest-hit rays are unbounded (t2 = DBL_MAX like cast_Ray / BSDF rays), any-hit rays use t2[i] (Render.cpp:219-221).
  * Same outputs as mcpt_probe_trace. */
@@ -222,7 +222,7 @@ mcpt_status mcpt_probe_bsdf(mcpt_ctx* ctx, uint32_t n, const float* normal, cons
 mcpt_status mcpt_probe_sample_light(mcpt_ctx* ctx, uint32_t n, const double* point, const float* xi, float* out10);
 /* One full path per item through the shipping integrator from a given ray, random numbers from the counter-based
  * generator keyed (seed, pixel = item, sample = 0).  out: L[3].  Runs the production wavefront pipeline (wf_shade_kernel +
- * wf_trace_kernel over a path pool, item = entry of an n x 1 film); the cross-check megakernel only under MCPT_PIPELINE=mega. */
+ * wf_trace8_kernel over a path pool, item = entry of an n x 1 film); the cross-check megakernel only under MCPT_PIPELINE=mega. */
 mcpt_status mcpt_probe_paths(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, uint64_t seed, float* out_L3);
 /* Texture::get_color (model.cpp:30-41) of material `material`'s Map_Kd for n (u, v) pairs (fp32, as the device interpolates them):
  * nearest texel, fract + clamp01's 0.999 cap, no v flip; a 1x1 texture returns its constant colour. */

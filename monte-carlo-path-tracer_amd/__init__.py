@@ -342,7 +342,7 @@ class Renderer:
         return ot, tri, u, v
 
     def probe_trace4(self, origin, direction, t2=None, any_hit=False):
-        """BVH::hit / has_hit through the production wf_trace_kernel (4-wide quantised tree)."""
+        """BVH::hit / has_hit through the production wf_trace8_kernel (8-wide compressed tree)."""
         o = np.ascontiguousarray(origin, np.float64).reshape(-1, 3); d = np.ascontiguousarray(direction, np.float64).reshape(-1, 3)
         n = o.shape[0]
         t2 = np.full(n, np.finfo(np.float64).max) if t2 is None else np.ascontiguousarray(t2, np.float64)

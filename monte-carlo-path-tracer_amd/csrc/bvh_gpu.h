@@ -19,9 +19,6 @@ bool gpu_build_bvh2(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string
 // the one that minimises the merged box's surface area within a +-16 window.  The default of MCPT_FLAG_GPU_BVH_BUILD.
 bool gpu_build_ploc(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string& err);
 
-// The 4-wide collapse + 8-bit quantisation of build_bvh4 (scene_build.cpp) on the device, level by level: binary nodes in (host builder's
-// layout, root = node 0), nodes4 out (device_scene.h layout, breadth-first by level), plus the depth of the 4-wide tree.
-bool gpu_collapse_bvh4(const std::vector<f4h>& nodes2, std::vector<f4h>& nodes4, uint32_t& depth4, std::string& err);
 // The 8-wide collapse of build_bvh8 (scene_build.cpp) on the device: same dynamic programme, same octant slots, same numbering -- the records
 // and the leaf order are the host's bit for bit.  In/out: `nodes2` (renumbered binary tree; its leaf codes follow the new leaf order on return)
 // and `order` (leaf order); out: nodes8 (5 x 16 B per node) and the depth of the 8-wide tree.

@@ -10,7 +10,7 @@
 //   5. emit_kernel       Karras nodes covering <= MCPT_LEAF_MAX triangles become leaves; the others are compacted (exclusive scan)
 //                        and written in the host builder's 64-B node format (both child boxes in the parent, child codes)
 //
-// Everything downstream (breadth-first renumbering, collapse to the 4-wide quantised tree, triangle streams in leaf order) is the
+// Everything downstream (breadth-first renumbering, collapse to the 8-wide quantised tree, triangle streams in leaf order) is the
 // same host code that follows the SAH builder.  Traversal results do not depend on the tree (closest hit = min t), only its cost
 // does: LBVH trees cost ~1.3x the SAH tree's node visits (S-bath 0.59 M: +17 % render time), so MCPT_FLAG_GPU_BVH_BUILD uses the
 // SAH-costed PLOC builder further down (gpu_build_ploc: +4 %) and this one is kept behind MCPT_GPU_BVH=lbvh.
@@ -401,15 +401,8 @@ bool gpu_build_bvh2(const float* tri_boxes, uint32_t n, GpuBvh& out, std::string
 }
 
 
-// ---------------------------------------------------------------------------------------------- 4-wide collapse + quantisation
-// The device version of build_bvh4 (scene_build.cpp): level-synchronous, one thread per 4-wide node.  A node adopts the two children
-// of its binary source node, then keeps replacing the inner child of largest area by that child's two children until it has four;
-// the child boxes are quantised to 8 bits in the node's own frame, rounded outward exactly like the host code (same double
-// arithmetic, same "does the fp32 reconstruction still enclose the box" fix-up); inner children claim their records for the next
-// level from an atomic counter -- records are therefore numbered level by level (breadth-first: the first MCPT_TOP_NODES records are
-// the top levels the trace kernel keeps in LDS), in arbitrary order within a level.
+// ---------------------------------------------------------------------------------------------- helpers of the wide collapse
 namespace {
-struct C4Item { int node2, slot4; };
 struct KidD { int code; float lo[3], hi[3]; };
 __device__ __forceinline__ KidD kid_of(const float4* __restrict__ n2, int n, int k) {
     const float4 a = n2[4 * (size_t)n + k], z = n2[4 * (size_t)n + 2], c = n2[4 * (size_t)n + 3];
@@ -418,98 +411,7 @@ __device__ __forceinline__ KidD kid_of(const float4* __restrict__ n2, int n, int
     r.lo[0] = a.x; r.hi[0] = a.y; r.lo[1] = a.z; r.hi[1] = a.w; r.lo[2] = k == 0 ? z.x : z.z; r.hi[2] = k == 0 ? z.y : z.w;
     return r;
 }
-__global__ void collapse4_kernel(const float4* __restrict__ n2, const C4Item* __restrict__ items, uint32_t n_items, C4Item* __restrict__ next, uint32_t* __restrict__ next_count,
-                                 uint32_t* __restrict__ n4_count, uint32_t n4_capacity, float4* __restrict__ n4, uint32_t* __restrict__ overflow) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    const C4Item w = items[i];
-    KidD kids[4]; int nk = 2;
-    kids[0] = kid_of(n2, w.node2, 0); kids[1] = kid_of(n2, w.node2, 1);
-    while (nk < 4) {
-        int best = -1; double ba = -1.0;
-        for (int k = 0; k < nk; k++) if (kids[k].code >= 0) {
-            const double x = (double)kids[k].hi[0] - kids[k].lo[0], y = (double)kids[k].hi[1] - kids[k].lo[1], z = (double)kids[k].hi[2] - kids[k].lo[2];
-            const double a = 2.0 * (x * y + y * z + z * x);
-            if (a > ba) { ba = a; best = k; }
-        }
-        if (best < 0) break;
-        const int n = kids[best].code;
-        kids[best] = kid_of(n2, n, 0); kids[nk++] = kid_of(n2, n, 1);
-    }
-    // drop empty leaves (count 0: only the artificial second child of a single-leaf scene)
-    int m = 0;
-    for (int k = 0; k < nk; k++) if (!(kids[k].code < 0 && (((uint32_t)~kids[k].code) & 7u) == 0u)) { if (m != k) kids[m] = kids[k]; m++; }
-    nk = m;
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
-    for (int k = 0; k < nk; k++) for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], kids[k].lo[a]); hi[a] = fmaxf(hi[a], kids[k].hi[a]); }
-    if (nk == 0) for (int a = 0; a < 3; a++) lo[a] = hi[a] = 0.f;
-    uint32_t ebits[3]; double scale[3];
-    for (int a = 0; a < 3; a++) {
-        const double ext = (double)hi[a] - (double)lo[a];
-        int e = ext > 0 ? (int)ceil(log2(ext / 255.0)) : -100;
-        while (ext > 0 && ldexp(255.0, e) < ext) e++;
-        e = e < -126 ? -126 : (e > 127 ? 127 : e);
-        ebits[a] = (uint32_t)(e + 127); scale[a] = ldexp(1.0, e);
-    }
-    uint32_t q[6] = {0, 0, 0, 0, 0, 0}; int codes[4] = {~0, ~0, ~0, ~0}; uint32_t valid = 0;
-    for (int k = 0; k < nk; k++) {
-        valid |= 1u << k;
-        for (int a = 0; a < 3; a++) {
-            double ql = floor(((double)kids[k].lo[a] - (double)lo[a]) / scale[a]);
-            double qh = ceil(((double)kids[k].hi[a] - (double)lo[a]) / scale[a]);
-            while (ql > 0 && (float)((double)lo[a] + ql * scale[a]) > kids[k].lo[a]) ql -= 1;
-            while (qh < 255 && (float)((double)lo[a] + qh * scale[a]) < kids[k].hi[a]) qh += 1;
-            ql = fmin(255.0, fmax(0.0, ql)); qh = fmin(255.0, fmax(0.0, qh));
-            q[a] |= (uint32_t)ql << (8 * k); q[3 + a] |= (uint32_t)qh << (8 * k);
-        }
-        if (kids[k].code >= 0) {
-            const uint32_t slot = atomicAdd(n4_count, 1u);
-            if (slot >= n4_capacity) { *overflow = 1u; codes[k] = ~0; valid &= ~(1u << k); continue; }
-            codes[k] = (int)slot;
-            next[atomicAdd(next_count, 1u)] = C4Item{kids[k].code, (int)slot};
-        } else codes[k] = kids[k].code;
-    }
-    float4* r = n4 + 4 * (size_t)w.slot4;
-    r[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (valid << 24)));
-    r[1] = make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
-    r[2] = make_float4(__uint_as_float(q[4]), __uint_as_float(q[5]), 0.f, 0.f);
-    r[3] = make_float4(__int_as_float(codes[0]), __int_as_float(codes[1]), __int_as_float(codes[2]), __int_as_float(codes[3]));
-}
 }  // namespace
-
-bool gpu_collapse_bvh4(const std::vector<f4h>& nodes2, std::vector<f4h>& nodes4, uint32_t& depth4, std::string& err) {
-    const uint32_t n2 = (uint32_t)(nodes2.size() / 4);
-    if (n2 == 0) { err = "gpu_collapse_bvh4: empty binary tree"; return false; }
-    DBuf d_n2, d_n4, d_q0, d_q1, d_cnt;
-    CK(d_n2.alloc(64 * (size_t)n2)); CK(d_n4.alloc(64 * (size_t)n2));           // a 4-wide tree never has more nodes than its binary source
-    CK(d_q0.alloc(sizeof(C4Item) * (size_t)n2)); CK(d_q1.alloc(sizeof(C4Item) * (size_t)n2)); CK(d_cnt.alloc(16));
-    CK(hipMemcpy(d_n2.p, nodes2.data(), 64 * (size_t)n2, hipMemcpyHostToDevice));
-    const C4Item root{0, 0};
-    CK(hipMemcpy(d_q0.p, &root, sizeof root, hipMemcpyHostToDevice));
-    uint32_t init[4] = {0u, 1u, 0u, 0u};                                            // next_count, n4_count (root claimed), overflow, -
-    CK(hipMemcpy(d_cnt.p, init, sizeof init, hipMemcpyHostToDevice));
-    uint32_t n_items = 1; depth4 = 0;
-    C4Item* cur = d_q0.as<C4Item>(); C4Item* nxt = d_q1.as<C4Item>();
-    while (n_items > 0) {
-        depth4++;
-        hipLaunchKernelGGL(collapse4_kernel, dim3((n_items + 127) / 128), dim3(128), 0, 0, d_n2.as<float4>(), cur, n_items, nxt, d_cnt.as<uint32_t>(), d_cnt.as<uint32_t>() + 1,
-                           n2, d_n4.as<float4>(), d_cnt.as<uint32_t>() + 2);
-        CK(hipGetLastError());
-        uint32_t c[3];
-        CK(hipMemcpy(c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost));
-        if (c[2]) { err = "gpu_collapse_bvh4: node capacity exceeded (internal error)"; return false; }
-        n_items = c[0];
-        CK(hipMemset(d_cnt.p, 0, 4));
-        C4Item* t = cur; cur = nxt; nxt = t;
-        if (depth4 > 256) { err = "gpu_collapse_bvh4: tree too deep"; return false; }
-    }
-    uint32_t n4 = 0;
-    CK(hipMemcpy(&n4, d_cnt.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
-    nodes4.resize(4 * (size_t)n4);
-    CK(hipMemcpy(nodes4.data(), d_n4.p, 64 * (size_t)n4, hipMemcpyDeviceToHost));
-    return true;
-}
 
 
 // ---------------------------------------------------------------------------------------------- 8-wide collapse (round 3)

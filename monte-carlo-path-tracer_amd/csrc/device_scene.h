@@ -76,11 +76,6 @@ struct DevCamera {                 // Render::cast_Ray's per-frame constants hoi
     int32_t width, height;
 };
 
-// nodes4: 64 B / node of the 4-wide quantised tree (breadth-first numbering):
-//   f4[0] = origin x y z (fp32) | u32: biased exponents ex | ey << 8 | ez << 16 | valid mask << 24
-//   f4[1] = u32 x4: qlo.x qlo.y qlo.z qhi.x   (byte k = child k, box = origin + q * 2^e, rounded outward)
-//   f4[2] = u32 x2: qhi.y qhi.z | 2 spare
-//   f4[3] = i32 x4: child codes (>= 0 inner node4 index, < 0 leaf ~(first << 3 | count); count 0 = empty)
 // nodes8: 80 B / node of the 8-wide compressed tree (breadth-first numbering; Ylitie, Karras & Laine 2017 re-laid for gfx950), five 16-B records:
 //   r[0] = origin x y z (fp32: the frame's origin LESS 1024 steps -- plane q lies at origin + (1024 + q) scale, see WF8_CHILD in wavefront.hip)
 //          | u32: scale_x << 16 | scale_y   (each scale = 2^e as a bfloat16, i.e. the top half of the fp32)
@@ -93,7 +88,6 @@ struct DevCamera {                 // Render::cast_Ray's per-frame constants hoi
 //   back in the order of s ^ (its direction octant).
 struct DevScene {
     const float4* nodes;
-    const float4* nodes4;
     const float4* nodes8;
     const float4* tri_isect;
     const float4* tri_shade;
@@ -110,7 +104,7 @@ struct DevScene {
                                    // works in fp64 world coordinates, where its absolute ray epsilon t1 = 1e-4 (Render.h:30) is translation-invariant;
                                    // fp32 keeps that property only while |coordinate| * 2^-24 << 1e-4.  World-space values the reference itself
                                    // rounds to fp32 (the light point and hit point of Render::sample) get the centre added back first (sample_light).
-    int32_t n_tris, n_lights, n_nodes, n_mats, n_nodes4, n_nodes8;
+    int32_t n_tris, n_lights, n_nodes, n_mats, n_nodes8;
 };
 
 struct RenderParams {

@@ -29,7 +29,7 @@ struct mcpt_ctx {
     int device = 0;
     mcpt_opts opts{};
     DevScene dev{};
-    DevBuf nodes, nodes4, nodes8, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, light_pos64, texels, accum_own, counters;
+    DevBuf nodes, nodes8, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, light_pos64, texels, accum_own, counters;
     float4* accum = nullptr;           // bound accumulator (own or external)
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -65,7 +65,7 @@ struct mcpt_ctx {
     double last_trace_ms = 0.0, total_trace_ms = 0.0, last_shade_ms = 0.0, total_shade_ms = 0.0;
     uint64_t total_iterations = 0;
     bool binary_ok = true;                // the binary cross-check tree fits its kernels' stack (false: a deep device-built tree)
-    uint32_t wide_width = 8, wide_depth = 0;   // the wide tree the wavefront trace kernel walks
+    uint32_t wide_depth = 0;              // depth of the 8-wide tree the wavefront trace kernel walks
     std::vector<int32_t> h_tri_face;      // leaf order -> face index, fetched on first use by mcpt_probe_trace4
 };
 
@@ -86,7 +86,7 @@ hipError_t upload(DevBuf& b, const std::vector<T>& v) {
 void destroy_ctx(mcpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    c->nodes.free_(); c->nodes4.free_(); c->nodes8.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_plane64.free_(); c->tri_face.free_();
+    c->nodes.free_(); c->nodes8.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_plane64.free_(); c->tri_face.free_();
     c->mats.free_(); c->lights.free_(); c->light_pos64.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
     for (auto& L : c->lanes) {
         for (auto& b : L.pool_bufs) b.free_();
@@ -179,7 +179,7 @@ static mcpt_status finish_ctx(mcpt_ctx* c) {
             // waves per SIMD (4 x 80 + 2 x 96 = 512).  Rounds 1-2 launched 3/4 and 7/8 of the CUs while the traversal data was
             // cache-resident (their 72-register kernel left room for a second block on some CUs); r03, 8-wide kernel, S-cornell 512 spp:
             // 214.6 / 217.5 / 211.6 / 213.4 / 208.5 ms at 192 / 208 / 224 / 240 / 256 blocks.  MCPT_WF_GRID overrides.
-            const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((c->opts.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0, c->wide_width));
+            const uint32_t per_cu = uint32_t(wf_trace_blocks_per_cu((c->opts.flags & MCPT_FLAG_COUNT_TRAVERSAL) != 0));
             c->trace_grid = uint32_t(c->n_cus) * per_cu;
             c->trace_grid = std::min(env_u32("MCPT_WF_GRID", c->trace_grid), uint32_t(c->n_cus) * per_cu);
             // speculative traversal: S-cornell 469 -> 450 ms; on the 4 M-triangle configuration, where the extra node visits are HBM
@@ -197,7 +197,7 @@ static mcpt_status finish_ctx(mcpt_ctx* c) {
                 if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
                 // the global overflow area of the traversal stack is sized from the wide tree's depth (2 x depth + 3 entries of 8 B per trace lane): a
                 // pathologically deep device-built tree (depth in the hundreds) would ask for a GB per sub-pipeline -- refuse instead of allocating it
-                const size_t ovf_bytes = size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_bytes_per_lane(c->wide_depth, c->wide_width);
+                const size_t ovf_bytes = size_t(c->trace_grid) * wf_trace_block_threads() * wf_trace_overflow_bytes_per_lane(c->wide_depth);
                 if (ovf_bytes > (size_t(512) << 20)) return fail(MCPT_ERR_BVH_DEPTH, "wide BVH of depth " + std::to_string(c->wide_depth) + " needs a traversal-stack overflow area of " + std::to_string(ovf_bytes >> 20) + " MB per sub-pipeline: build the tree with the host builder (no MCPT_FLAG_GPU_BVH_BUILD)");
                 if ((e = L.ovf_buf.alloc(ovf_bytes)) != hipSuccess)
                     return bail(e, "alloc stack overflow area");
@@ -207,24 +207,24 @@ static mcpt_status finish_ctx(mcpt_ctx* c) {
     if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "sync after upload");
     c->accum = static_cast<float4*>(c->accum_own.p);
     DevScene& d = c->dev;
-    d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes4 = static_cast<const float4*>(c->nodes4.p); d.nodes8 = static_cast<const float4*>(c->nodes8.p);
+    d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes8 = static_cast<const float4*>(c->nodes8.p);
     d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
     d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p); d.tri_plane64 = static_cast<const double*>(c->tri_plane64.p);
     d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
     d.lights = static_cast<const DevLight*>(c->lights.p); d.light_pos64 = static_cast<const double*>(c->light_pos64.p); d.texels = static_cast<const float4*>(c->texels.p);
-    c->info.device_bytes = c->nodes.bytes + c->nodes4.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes +
+    c->info.device_bytes = c->nodes.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes +
                            c->mats.bytes + c->lights.bytes + c->light_pos64.bytes + c->texels.bytes + accum_bytes;
     return MCPT_OK;
 }
 
 static void fill_wide_info(mcpt_scene_info& in, const HostScene& hs) {
-    in.wide_width = hs.bvh_width; in.wide_nodes = uint32_t(hs.bvh_width == 8 ? hs.nodes8.size() / 5 : hs.nodes4.size() / 4);
-    in.wide_depth = hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth;
-    in.traversal_bytes = (hs.nodes4.size() + hs.nodes8.size() + hs.tri_isect.size()) * sizeof(f4h);
+    in.wide_width = 8; in.wide_nodes = uint32_t(hs.nodes8.size() / 5);
+    in.wide_depth = hs.bvh8_depth;
+    in.traversal_bytes = (hs.nodes8.size() + hs.tri_isect.size()) * sizeof(f4h);
     for (int a = 0; a < 3; a++) in.centre[a] = hs.centre[a];
     uint64_t h = 1469598103934665603ull;                                  // FNV-1a, 4 bytes at a time
     auto mix = [&](const void* p, size_t bytes) { const uint32_t* w = static_cast<const uint32_t*>(p); for (size_t i = 0; i < bytes / 4; i++) { h ^= w[i]; h *= 1099511628211ull; } };
-    mix(hs.nodes8.data(), hs.nodes8.size() * sizeof(f4h)); mix(hs.nodes4.data(), hs.nodes4.size() * sizeof(f4h)); mix(hs.tri_face.data(), hs.tri_face.size() * 4);
+    mix(hs.nodes8.data(), hs.nodes8.size() * sizeof(f4h)); mix(hs.tri_face.data(), hs.tri_face.size() * 4);
     in.wide_tree_hash = h;
 }
 
@@ -236,7 +236,6 @@ const char* mcpt_last_error(void) { return g_err.c_str(); }
 mcpt_status mcpt_check_scene(const mcpt_scene_desc* scene, mcpt_scene_info* out_info) {
     if (!scene) return fail(MCPT_ERR_INVALID_ARG, "mcpt_check_scene: null argument");
     HostScene hs; std::string err;
-    hs.bvh_width = env_u32("MCPT_BVH_WIDTH", 8) == 4 ? 4u : 8u;
     mcpt_status st = build_host_scene(scene, hs, err);
     if (st != MCPT_OK) return fail(st, err);
     const std::string bad = validate_wide_bvh(hs);
@@ -259,7 +258,6 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if (o.integrator > MCPT_INTEGRATOR_RECURSIVE_NEE) return fail(MCPT_ERR_INVALID_ARG, "unknown integrator");
 
     HostScene hs; std::string err;
-    hs.bvh_width = env_u32("MCPT_BVH_WIDTH", 8) == 4 ? 4u : 8u;          // developer knob: 4 = the round-2 4-wide tree and its kernel
     hs.reference_tie_order = (o.flags & MCPT_FLAG_REFERENCE_TIE_ORDER) != 0;
     // which pipeline this context runs is decided ONCE, here: it sets how deep a device-built binary tree may be (below) and which kernels
     // mcpt_render launches -- the two must agree, or a megakernel context could walk a tree deeper than its LDS stack
@@ -288,8 +286,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
             if (!(lbvh ? gpu_build_bvh2(boxes, n, g, berr) : gpu_build_ploc(boxes, n, g, berr))) return false;
             nodes.swap(g.nodes); order.assign(g.order.begin(), g.order.end()); depth = g.depth; max_leaf = g.max_leaf;
             return true;
-        }, env_u32("MCPT_HOST_COLLAPSE", 0) ? Collapse4Fn(nullptr) : Collapse4Fn(gpu_collapse_bvh4),
-           env_u32("MCPT_HOST_COLLAPSE", 0) ? Collapse8Fn(nullptr) : Collapse8Fn(gpu_collapse_bvh8));
+        }, env_u32("MCPT_HOST_COLLAPSE", 0) ? Collapse8Fn(nullptr) : Collapse8Fn(gpu_collapse_bvh8));
         if (st != MCPT_OK) return fail(st, err);
         if (env_u32("MCPT_VALIDATE_BVH", 0)) { const std::string bad = validate_wide_bvh(hs); if (!bad.empty()) return fail(MCPT_ERR_HIP, "device-built BVH failed validation: " + bad); }
     } else {
@@ -299,16 +296,15 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     }
 
     // the 8-wide trace kernel addresses node and triangle records with 32-bit byte offsets
-    if (hs.bvh_width == 8 && (hs.nodes8.size() * sizeof(f4h) >= (1ull << 32) || hs.tri_isect.size() * sizeof(f4h) >= (1ull << 32)))
+    if ((hs.nodes8.size() * sizeof(f4h) >= (1ull << 32) || hs.tri_isect.size() * sizeof(f4h) >= (1ull << 32)))
         return fail(MCPT_ERR_UNSUPPORTED, "scene too large for the 8-wide traversal kernel (more than 89 M triangles)");
     mcpt_ctx* c = new mcpt_ctx();
     c->device = o.device; c->opts = o; c->width = scene->camera.width; c->height = scene->camera.height;
-    c->wide_width = hs.bvh_width; c->wide_depth = hs.bvh_width == 8 ? hs.bvh8_depth : hs.bvh4_depth; c->binary_ok = hs.binary_ok; c->use_wavefront = use_wavefront;
+    c->wide_depth = hs.bvh8_depth; c->binary_ok = hs.binary_ok; c->use_wavefront = use_wavefront;
     auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };
     if ((e = hipSetDevice(c->device)) != hipSuccess) return bail(e, "hipSetDevice");
     auto t0 = std::chrono::steady_clock::now();
     if ((e = upload(c->nodes, hs.nodes)) != hipSuccess) return bail(e, "upload nodes");
-    if ((e = upload(c->nodes4, hs.nodes4)) != hipSuccess) return bail(e, "upload nodes4");
     if ((e = upload(c->nodes8, hs.nodes8)) != hipSuccess) return bail(e, "upload nodes8");
     if ((e = upload(c->tri_isect, hs.tri_isect)) != hipSuccess) return bail(e, "upload tri_isect");
     if ((e = upload(c->tri_shade, hs.tri_shade)) != hipSuccess) return bail(e, "upload tri_shade");
@@ -320,7 +316,7 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if ((e = upload(c->light_pos64, hs.light_pos64)) != hipSuccess) return bail(e, "upload light corners");
     if ((e = upload(c->texels, hs.texels)) != hipSuccess) return bail(e, "upload texels");
     DevScene& d = c->dev;
-    d.n_nodes4 = int32_t(hs.nodes4.size() / 4); d.n_nodes8 = int32_t(hs.nodes8.size() / 5);
+    d.n_nodes8 = int32_t(hs.nodes8.size() / 5);
     d.cam = hs.cam;
     for (int a = 0; a < 3; a++) d.centre[a] = hs.centre[a];
     d.n_tris = int32_t(hs.tri_face.size()); d.n_lights = int32_t(hs.lights.size()); d.n_nodes = int32_t(hs.nodes.size() / 4); d.n_mats = int32_t(hs.mats.size());
@@ -349,14 +345,14 @@ mcpt_status mcpt_clone_to_device(mcpt_ctx* src, int32_t device, mcpt_ctx** out_c
     HIP_TRY(hipStreamSynchronize(src->stream));
     mcpt_ctx* c = new mcpt_ctx();
     c->device = device; c->opts = src->opts; c->opts.device = device; c->width = src->width; c->height = src->height;
-    c->wide_width = src->wide_width; c->wide_depth = src->wide_depth; c->binary_ok = src->binary_ok; c->use_wavefront = src->use_wavefront;
+    c->wide_depth = src->wide_depth; c->binary_ok = src->binary_ok; c->use_wavefront = src->use_wavefront;
     c->dev = src->dev; c->info = src->info; c->info.bvh_build_ms = 0.0;
     auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     auto t0 = std::chrono::steady_clock::now();
-    DevBuf* from[12] = {&src->nodes, &src->nodes4, &src->nodes8, &src->tri_isect, &src->tri_shade, &src->tri_pos64, &src->tri_plane64, &src->tri_face, &src->mats, &src->lights, &src->light_pos64, &src->texels};
-    DevBuf* to[12] = {&c->nodes, &c->nodes4, &c->nodes8, &c->tri_isect, &c->tri_shade, &c->tri_pos64, &c->tri_plane64, &c->tri_face, &c->mats, &c->lights, &c->light_pos64, &c->texels};
-    for (int i = 0; i < 12; i++) {
+    DevBuf* from[11] = {&src->nodes, &src->nodes8, &src->tri_isect, &src->tri_shade, &src->tri_pos64, &src->tri_plane64, &src->tri_face, &src->mats, &src->lights, &src->light_pos64, &src->texels};
+    DevBuf* to[11] = {&c->nodes, &c->nodes8, &c->tri_isect, &c->tri_shade, &c->tri_pos64, &c->tri_plane64, &c->tri_face, &c->mats, &c->lights, &c->light_pos64, &c->texels};
+    for (int i = 0; i < 11; i++) {
         if ((e = to[i]->alloc(from[i]->bytes)) != hipSuccess) return bail(e, "alloc scene stream");
         if (from[i]->bytes && (e = hipMemcpyPeer(to[i]->p, device, from[i]->p, src->device, from[i]->bytes)) != hipSuccess) return bail(e, "hipMemcpyPeer");
     }
@@ -766,7 +762,7 @@ mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, co
 }
 
 // The PRODUCTION traversal: the caller's rays are written into a path pool exactly as wf_shade_kernel would leave them (extend rays
-// in ray_o / ray_d, shadow rays in sh_d + the per-block shadow queue), wf_trace_kernel runs once over that pool, and the results
+// in ray_o / ray_d, shadow rays as sq_o / sq_d records of the per-block shadow queue), wf_trace8_kernel runs once over that pool, and the results
 // are read back from where wf_shade_kernel would pick them up (pool.hit; for shadow rays the L += nee the unoccluded ones perform).
 mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir, const double* t2, int any_hit,
                               float* out_t, int32_t* out_tri, float* out_u, float* out_v) {

@@ -91,7 +91,7 @@ DEV void cast_ray(const DevCamera& c, int x, int y, float xi_x, float xi_y, d3& 
 struct TravCount { uint32_t box, tri; };
 
 // Moller-Trumbore against one 48-B {v0, e1, e2} record -- the ONE triangle test of this library, shared by the binary-tree
-// traversal below and the 4-wide wavefront trace kernel (wavefront.hip).  Triangle::hit / isIntersect compute the same
+// traversal below and the wavefront trace kernel (wf_trace8_kernel, wavefront.hip).  Triangle::hit / isIntersect compute the same
 // quantities in fp64 (Triangle.cpp:48-66, :83-104); the acceptance rules are the reference's, see tri_accept_*.
 struct TriTest { float a, t, u, v; };
 DEV TriTest tri_test(const float4 v0, const float4 e1, const float4 e2, const f3 o, const f3 d) {

@@ -189,11 +189,7 @@ template <class F> void parallel_for(uint32_t n, F&& body) {
 
 inline double len3(const double* v) { return std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
 
-// ---- 4-wide, quantised BVH for the wavefront trace kernel (device_scene.h: nodes4) --------------------------------------------
-// Collapsed from the binary SAH tree: a node adopts its two children, then repeatedly replaces the inner child with the largest
-// surface area by that child's two children until it has four (or only leaves are left).  Child boxes are stored as 8-bit
-// offsets in the node's own frame (origin = box minimum, per-axis power-of-two scale), rounded OUTWARD, so a 4-child node is
-// one 64-B record: 2x fewer node visits, vector-memory instructions and scheduling rounds per ray than the 64-B binary node.
+// ---- helpers of the wide collapse: the binary tree's records --------------------------------------------------------------------
 struct Box3f { float lo[3], hi[3]; };
 inline int child2(const std::vector<f4h>& n2, int n, int k) { int c; std::memcpy(&c, k == 0 ? &n2[4 * size_t(n) + 3].x : &n2[4 * size_t(n) + 3].y, 4); return c; }
 inline Box3f box2(const std::vector<f4h>& n2, int n, int k) {
@@ -207,13 +203,10 @@ inline double area3(const Box3f& b) { const double x = double(b.hi[0]) - b.lo[0]
 inline uint32_t as_u32(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float from_u32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
-// Which binary nodes become 4-wide nodes: SAH-optimal collapse (dynamic programme over the slot budget, Wald et al. 2008 / Ylitie et al.
+// Which binary nodes become K-wide nodes: SAH-optimal collapse (dynamic programme over the slot budget, Wald et al. 2008 / Ylitie et al.
 // 2017; leaves stay as the builder made them).  cost[n][i] = least expected number of node visits (sum of relative surface areas of the
-// 4-wide nodes created) for the subtree of binary node n when it may occupy i of its 4-wide parent's slots: i = 1 makes n a node of its
+// K-wide nodes created) for the subtree of binary node n when it may occupy i of its K-wide parent's slots: i = 1 makes n a node of its
 // own, i > 1 dissolves it and lets its two children share the slots.  split[n][i] = slots given to the left child (0 = "as for i - 1").
-// Against adopting the children of the largest inner child until the node is full (the default, and the device collapse's rule):
-// 3.5 instead of 2.9 of 4 slots filled, ~20 % fewer nodes, -3 % / -8 % closest-hit / any-hit steps per ray on S-cornell
-// (tools/wide_bvh_probe.sh) -- and no faster on the device, see build_bvh4.
 struct CollapsePlan {
     int K = 4;
     std::vector<unsigned char> split;                                   // [n * (K + 1) + i]
@@ -270,81 +263,6 @@ void planned_kids(const std::vector<f4h>& n2, const CollapsePlan& plan, int node
         if (c < 0 || i == 1) { kids.push_back({c, box2(n2, it.parent, it.k)}); continue; }
         const int a = plan.at(c, i);
         todo.push_back({c, 1, i - a}); todo.push_back({c, 0, a});
-    }
-}
-
-void build_bvh4(HostScene& out) {
-    const std::vector<f4h>& n2 = out.nodes;
-    std::vector<f4h>& n4 = out.nodes4;
-    n4.clear();
-    struct Work { int node2, slot4; uint32_t depth; };
-    // Default: adopt the children of the largest inner child until the node is full.  MCPT_COLLAPSE=sah (developer knob) follows the
-    // SAH-optimal plan instead: measured on MI355X -1 % on S-cornell (fuller nodes = more valid boxes to test per visit: 31.8 vs 30.7 box
-    // tests per ray, though 3 - 8 % fewer visits), +-0 on S-veach and S-bath 0.59 M, +1 % on S-bath 4 M (20 % fewer node bytes).
-    const char* mode = std::getenv("MCPT_COLLAPSE");
-    const bool optimal = mode && std::string(mode) == "sah";
-    const CollapsePlan plan = optimal ? plan_collapse(n2, 4) : CollapsePlan();
-    // breadth-first emission => the first MCPT_TOP_NODES records are the top levels (LDS-resident in the trace kernel)
-    std::vector<Work> queue{{0, 0, 1}};
-    n4.resize(4);
-    out.bvh4_depth = 1;
-    for (size_t qh = 0; qh < queue.size(); qh++) {
-        const Work w = queue[qh];
-        out.bvh4_depth = std::max(out.bvh4_depth, w.depth);
-        std::vector<Kid> kids;
-        if (optimal) planned_kids(n2, plan, w.node2, kids);             // follow the plan: the roots of the forest below w.node2 that fills 4 slots
-        else {
-            for (int k = 0; k < 2; k++) kids.push_back({child2(n2, w.node2, k), box2(n2, w.node2, k)});
-            while (kids.size() < 4) {
-                int best = -1; double ba = -1.0;
-                for (size_t i = 0; i < kids.size(); i++) if (kids[i].code >= 0) { const double a = area3(kids[i].box); if (a > ba) { ba = a; best = int(i); } }
-                if (best < 0) break;
-                const int n = kids[best].code;
-                kids[best] = {child2(n2, n, 0), box2(n2, n, 0)};
-                kids.push_back({child2(n2, n, 1), box2(n2, n, 1)});
-            }
-        }
-        // drop empty leaves (count 0: only the artificial second child of a single-leaf scene)
-        for (size_t i = 0; i < kids.size();) { if (kids[i].code < 0 && ((uint32_t(~kids[i].code)) & 7u) == 0) kids.erase(kids.begin() + i); else i++; }
-        // frame
-        float lo[3], hi[3];
-        for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
-        for (const Kid& k : kids) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], k.box.lo[a]); hi[a] = std::max(hi[a], k.box.hi[a]); }
-        if (kids.empty()) { for (int a = 0; a < 3; a++) lo[a] = hi[a] = 0.f; }
-        uint32_t ebits[3]; double scale[3];
-        for (int a = 0; a < 3; a++) {
-            const double ext = double(hi[a]) - double(lo[a]);
-            int e = ext > 0 ? int(std::ceil(std::log2(ext / 255.0))) : -100;
-            while (ext > 0 && std::ldexp(255.0, e) < ext) e++;                       // guard log2 rounding
-            e = std::max(-126, std::min(127, e));
-            ebits[a] = uint32_t(e + 127); scale[a] = std::ldexp(1.0, e);
-        }
-        uint32_t q[6] = {0, 0, 0, 0, 0, 0};      // qlo x,y,z ; qhi x,y,z -- byte k = child k
-        int codes[4] = {~0, ~0, ~0, ~0};         // ~0 = leaf with count 0 = empty slot
-        uint32_t valid = 0;
-        for (size_t i = 0; i < kids.size(); i++) {
-            valid |= 1u << i;
-            for (int a = 0; a < 3; a++) {
-                double ql = std::floor((double(kids[i].box.lo[a]) - double(lo[a])) / scale[a]);
-                double qhv = std::ceil((double(kids[i].box.hi[a]) - double(lo[a])) / scale[a]);
-                // make sure the fp32 reconstruction lo + q*scale still encloses the child box
-                while (ql > 0 && float(double(lo[a]) + ql * scale[a]) > kids[i].box.lo[a]) ql -= 1;
-                while (qhv < 255 && float(double(lo[a]) + qhv * scale[a]) < kids[i].box.hi[a]) qhv += 1;
-                ql = std::min(255.0, std::max(0.0, ql)); qhv = std::min(255.0, std::max(0.0, qhv));
-                q[a] |= uint32_t(ql) << (8 * i); q[3 + a] |= uint32_t(qhv) << (8 * i);
-            }
-            if (kids[i].code >= 0) {                   // inner child: reserve its record, process later
-                const int slot = int(n4.size() / 4);
-                n4.resize(n4.size() + 4);
-                codes[i] = slot;
-                queue.push_back({kids[i].code, slot, w.depth + 1});
-            } else codes[i] = kids[i].code;
-        }
-        f4h* r = &n4[4 * size_t(w.slot4)];
-        r[0] = {lo[0], lo[1], lo[2], from_u32(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (valid << 24))};
-        r[1] = {from_u32(q[0]), from_u32(q[1]), from_u32(q[2]), from_u32(q[3])};
-        r[2] = {from_u32(q[4]), from_u32(q[5]), 0.f, 0.f};
-        r[3] = {as_float(codes[0]), as_float(codes[1]), as_float(codes[2]), as_float(codes[3])};
     }
 }
 
@@ -486,52 +404,8 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
 
 }  // namespace
 
-// Self-check used by mcpt_check_scene: walk the 4-wide tree exactly as the kernel dequantises it (fp32: origin + q * 2^e) and verify
-// that every leaf triangle's fp32 test data (v0, v0+e1, v0+e2) lies inside every box on its root path, that every triangle is
-// referenced exactly once, and that child links are in range.  Returns an empty string when the tree is sound.
-std::string validate_bvh4(const HostScene& hs) {
-    const size_t n4 = hs.nodes4.size() / 4, nt = hs.tri_face.size();
-    if (n4 == 0) return "empty nodes4";
-    std::vector<uint8_t> seen(nt, 0);
-    struct Item { int node; float lo[3], hi[3]; };
-    std::vector<Item> stack;
-    Item root; root.node = 0; for (int a = 0; a < 3; a++) { root.lo[a] = -INFINITY; root.hi[a] = INFINITY; }
-    stack.push_back(root);
-    size_t visited = 0;
-    while (!stack.empty()) {
-        const Item it = stack.back(); stack.pop_back();
-        if (it.node < 0 || size_t(it.node) >= n4) return "child link out of range";
-        if (++visited > n4) return "cycle in nodes4";
-        const f4h* r = &hs.nodes4[4 * size_t(it.node)];
-        const uint32_t meta = as_u32(r[0].w);
-        const float sc[3] = {from_u32((meta & 0xffu) << 23), from_u32(((meta >> 8) & 0xffu) << 23), from_u32(((meta >> 16) & 0xffu) << 23)};
-        const float org[3] = {r[0].x, r[0].y, r[0].z};
-        const uint32_t q[6] = {as_u32(r[1].x), as_u32(r[1].y), as_u32(r[1].z), as_u32(r[1].w), as_u32(r[2].x), as_u32(r[2].y)};
-        const int codes[4] = {int(as_u32(r[3].x)), int(as_u32(r[3].y)), int(as_u32(r[3].z)), int(as_u32(r[3].w))};
-        for (int k = 0; k < 4; k++) {
-            if (!((meta >> (24 + k)) & 1u)) continue;
-            Item ch; ch.node = codes[k];
-            for (int a = 0; a < 3; a++) {
-                const float lo = org[a] + float((q[a] >> (8 * k)) & 0xffu) * sc[a], hi = org[a] + float((q[3 + a] >> (8 * k)) & 0xffu) * sc[a];
-                ch.lo[a] = std::max(it.lo[a], lo); ch.hi[a] = std::min(it.hi[a], hi);     // a point must be inside EVERY box on the path
-            }
-            if (codes[k] >= 0) { stack.push_back(ch); continue; }
-            const uint32_t leaf = uint32_t(~codes[k]), first = leaf >> 3, cnt = leaf & 7u;
-            if (size_t(first) + cnt > nt) return "leaf range out of bounds";
-            for (uint32_t t = first; t < first + cnt; t++) {
-                if (seen[t]++) return "triangle referenced twice";
-                const f4h v0 = hs.tri_isect[3 * size_t(t)], e1 = hs.tri_isect[3 * size_t(t) + 1], e2 = hs.tri_isect[3 * size_t(t) + 2];
-                const float P[3][3] = {{v0.x, v0.y, v0.z}, {v0.x + e1.x, v0.y + e1.y, v0.z + e1.z}, {v0.x + e2.x, v0.y + e2.y, v0.z + e2.z}};
-                for (int c = 0; c < 3; c++) for (int a = 0; a < 3; a++)
-                    if (!(P[c][a] >= ch.lo[a] && P[c][a] <= ch.hi[a])) return "triangle " + std::to_string(t) + " sticks out of a quantised box on its path";
-            }
-        }
-    }
-    for (size_t t = 0; t < nt; t++) if (!seen[t]) return "triangle " + std::to_string(t) + " not reachable";
-    return "";
-}
-
-// The same soundness walk for the 8-wide tree: boxes dequantised the way wf_trace_kernel does, children and triangles located the way it
+// Self-check used by mcpt_check_scene -- the soundness walk of the 8-wide tree (every leaf triangle's fp32 test data inside every box on its
+// root path, every triangle referenced exactly once, child links in range; empty string = sound): boxes dequantised the way wf_trace8_kernel does, children and triangles located the way it
 // locates them (child_base + rank among the inner slots; tri_base + the counts of the lower leaf slots).
 std::string validate_bvh8(const HostScene& hs) {
     const size_t n8 = hs.nodes8.size() / 5, nt = hs.tri_face.size();
@@ -624,8 +498,7 @@ static void reference_triangle_order(const mcpt_scene_desc* d, std::vector<uint3
     for (uint32_t i = 0; i < nf; i++) rank[size_t(ord[i])] = i;
 }
 
-mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh, const Collapse4Fn& custom_collapse,
-                             const Collapse8Fn& custom_collapse8) {
+mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::string& err, const BvhBuildFn& custom_bvh, const Collapse8Fn& custom_collapse8) {
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
     if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }
     if (d->camera.width <= 0 || d->camera.height <= 0) { err = "camera width/height must be positive"; return MCPT_ERR_INVALID_ARG; }
@@ -755,14 +628,11 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     out.binary_ok = out.bvh_depth <= uint32_t(MCPT_STACK_DEPTH - 1);
     if (!out.binary_ok && !out.allow_deep_binary) { err = "BVH depth exceeds traversal stack"; return MCPT_ERR_BVH_DEPTH; }
-    out.nodes4.clear(); out.nodes8.clear(); out.bvh4_depth = out.bvh8_depth = 0;
-    if (out.bvh_width == 8 && custom_collapse8) { if (!custom_collapse8(out.nodes, order, out.nodes8, out.bvh8_depth, err)) return MCPT_ERR_HIP; }
-    else if (out.bvh_width == 8) build_bvh8(out, order);                  // (defines the leaf order: `order` and the binary leaf codes are rewritten)
-    else if (custom_collapse) { if (!custom_collapse(out.nodes, out.nodes4, out.bvh4_depth, err)) return MCPT_ERR_HIP; }
-    else build_bvh4(out);
-    if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] %u-wide collapse done at %.0f ms (%zu nodes, depth %u)\n", out.bvh_width,
-                                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-                                                 out.bvh_width == 8 ? out.nodes8.size() / 5 : out.nodes4.size() / 4, out.bvh_width == 8 ? out.bvh8_depth : out.bvh4_depth);
+    out.nodes8.clear(); out.bvh8_depth = 0;
+    if (custom_collapse8) { if (!custom_collapse8(out.nodes, order, out.nodes8, out.bvh8_depth, err)) return MCPT_ERR_HIP; }
+    else build_bvh8(out, order);                                          // (defines the leaf order: `order` and the binary leaf codes are rewritten)
+    if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] 8-wide collapse done at %.0f ms (%zu nodes, depth %u)\n",
+                                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), out.nodes8.size() / 5, out.bvh8_depth);
     std::vector<int> pos_of_face(nf);
     for (uint32_t i = 0; i < nf; i++) pos_of_face[order[i]] = int(i);
 

@@ -63,6 +63,6 @@ hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const Path
                            float4* accum, DevCounters* cnt, hipStream_t stream);
 hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,
                            DevCounters* cnt, uint32_t grid_blocks, int* stack_overflow, hipStream_t stream);
-int wf_trace_blocks_per_cu(bool count, uint32_t width);
+int wf_trace_blocks_per_cu(bool count);
 uint32_t wf_trace_block_threads();
-size_t wf_trace_overflow_bytes_per_lane(uint32_t wide_depth, uint32_t width);
+size_t wf_trace_overflow_bytes_per_lane(uint32_t wide_depth);

@@ -16,7 +16,6 @@
 //                    leaf block once enough lanes cannot go on without their (parked) leaf, and the refill block (write results back, pull
 //                    fresh rays from a wave-private chunk of the list) once enough lanes are idle -- so the expensive blocks execute with
 //                    well-packed lanes.  71 VGPRs; 1024-thread blocks with 63 KB of LDS (top tree levels + per-lane stack).
-//   wf_trace_kernel  the round-2 kernel over the 4-wide quantised tree, kept behind MCPT_BVH_WIDTH=4 (developer knob, A/B baseline).
 // DESIGN.md §5 has the measurements behind each of these choices.
 #include "pt_device.h"
 #include "wavefront.h"
@@ -534,374 +533,17 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
 #undef SH_TICK
 
 // ====================================================================================================== trace
-// BVH_node::hit / has_hit (BVH.cpp:95-136), AABB::Intersection (AABB.cpp:25-36), Triangle::hit / isIntersect
-// (Triangle.cpp:48-106) for the whole ray list of one iteration.  Acceptance rules: see bvh_traverse in pt_device.h.
-// Block = WF_TRACE_BLOCK (1024) threads = 16 waves sharing one LDS image of the top MCPT_TOP_NODES (256) nodes (16 KB, quarter-major
-// so that lanes reading different nodes spread over the banks) + a WF_LDS_STACK (12)-entry per-lane stack (48 KB); deeper stack
-// entries (rare) spill to a global overflow area sized from the tree's depth.  Two blocks fit per CU; the host launches fewer when a
-// second sub-pipeline shares the GPU (mcpt_api.cpp).
 #ifndef WF_TRACE_BLOCK
 #define WF_TRACE_BLOCK 1024
 #endif
 #ifndef WF_CHUNK_BATCH
 #define WF_CHUNK_BATCH 4
 #endif
-#ifndef WF_LDS_STACK
-#define WF_LDS_STACK 12
-#endif
-template <bool COUNT>
-__global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
-                                                                  int* __restrict__ stack_overflow) {
-    if (ctl->any_active[it & 3u] == 0u) return;                       // no live slot after this iteration's shade call: no ray to trace (see wf_shade_kernel)
-    __shared__ int s_stack[WF_LDS_STACK * WF_TRACE_BLOCK];
-    __shared__ float4 s_top[4 * MCPT_TOP_NODES];                      // [quarter][node]
-    // explicit address spaces: with generic pointers hipcc folds `lds ? : global` into ONE flat_load (select of pointers), which is
-    // slower than either path and hides the LDS traffic from the LDS pipe -- typed pointers keep ds_read / global_load apart
-    typedef __attribute__((address_space(3))) int lds_i32;
-    typedef float v4f __attribute__((ext_vector_type(4)));             // native vector: loads through typed pointers compile
-    typedef __attribute__((address_space(3))) v4f lds_f4;
-    typedef __attribute__((address_space(1))) int glb_i32;
-    typedef __attribute__((address_space(1))) const v4f glb_cf4;
-    lds_i32* stk = (lds_i32*)s_stack + threadIdx.x;
-    lds_f4* top = (lds_f4*)s_top;
-    const uint32_t ovf_stride = gridDim.x * WF_TRACE_BLOCK;
-    // (the overflow area's per-lane base is recomputed where it is needed -- rarely -- instead of living in two registers)
-#define OVF(LEVEL) (((glb_i32*)stack_overflow)[(uint32_t)(LEVEL) * ovf_stride + (blockIdx.x * WF_TRACE_BLOCK + threadIdx.x)])   // 32-bit index math
-    glb_cf4* gnodes = (glb_cf4*)sc.nodes4;
-    const int n_top = sc.n_nodes4 < MCPT_TOP_NODES ? sc.n_nodes4 : MCPT_TOP_NODES;
-    for (int i = threadIdx.x; i < 4 * n_top; i += WF_TRACE_BLOCK) s_top[(i & 3) * MCPT_TOP_NODES + (i >> 2)] = sc.nodes4[i];
-    __syncthreads();
-#ifdef WF_SCHED_STATS
-    const unsigned long long t_start = wall_clock64();
-#endif
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t P = pool.P;
-    // Ray list = 2 * P / 256 chunks: chunk c < P/256 holds the extend rays of slots [256 c, 256 c + 256); chunk P/256 + b holds the
-    // shadow rays shade block b queued (shadow_count[b] of them).  A wave owns one chunk at a time: the first statically (no atomic),
-    // later ones from `head`.
-    // A list with fewer chunks than waves (a small call: one sample per pixel of a small film) is handed out in quarter chunks of 64 rays,
-    // so that every wave of the grid gets rays and no lane works four of them one after the other.
-    const uint32_t n_ext_chunks = P / WF_SHADE_BLOCK;
-    const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
-    const uint32_t sub_sh = 2 * n_ext_chunks < n_waves ? 2u : 0u;     // log2(parts per chunk)
-    const uint32_t n_chunks = (2 * n_ext_chunks) << sub_sh;
-    uint32_t* head = &ctl->trace_head[it & 3];
-    uint32_t w_next = 0, w_end = 0, q_base = 0;      // current chunk: item range [w_next, w_end); shadow chunks: queue offset q_base
-    bool chunk_shadow = false, exhausted = false;
-    auto take_chunk = [&](uint32_t c) {              // (straight-line on purpose: with early returns the compiler kept w_next / w_end in scratch)
-        const uint32_t cc = c >> sub_sh, part = c & ((1u << sub_sh) - 1u), span = (uint32_t)WF_SHADE_BLOCK >> sub_sh;
-        const bool none = c >= n_chunks, ext = cc < n_ext_chunks, shadow = !none && !ext;
-        const uint32_t b = shadow ? cc - n_ext_chunks : 0u;
-        uint32_t cnt = ext ? (uint32_t)WF_SHADE_BLOCK : 0u;
-        if (shadow) cnt = wave_first(ld_s(&pool.shadow_count[b]));
-        const uint32_t lo = min(part * span, cnt), hi = min(lo + span, cnt), base = ext ? cc * WF_SHADE_BLOCK : 0u;
-        exhausted = exhausted || none;
-        chunk_shadow = shadow;
-        q_base = b * WF_SHADE_BLOCK;
-        w_next = base + lo;
-        w_end = base + hi;
-    };
-    // chunks are reserved `batch` at a time: WF_CHUNK_BATCH when the list is long (one atomic on `head` per ~1-2 k rays per wave).  A short
-    // list (a one-sample-per-pixel call: 5 000 chunks for 3 584 waves) would leave most waves -- whole CUs, with block-major wave numbers --
-    // without a first chunk: there every wave takes n_chunks / n_waves (at least one) and wave numbers interleave across the blocks.
-    const bool short_list = n_chunks < n_waves * WF_CHUNK_BATCH;
-    const uint32_t batch = short_list ? max(1u, n_chunks / n_waves) : (uint32_t)WF_CHUNK_BATCH;
-    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: the chunk bookkeeping below stays in SGPRs
-    const uint32_t wave_id = short_list ? wave_in_block * gridDim.x + blockIdx.x : blockIdx.x * (WF_TRACE_BLOCK / 64) + wave_in_block;
-    uint32_t c_next = wave_id * batch, c_end = c_next + batch;
-    take_chunk(c_next++);
-
-    bool have = false, any = false, blocked = false;
-    uint32_t slot = 0;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
-    float idx = 0, idy = 0, idz = 0, tmax = 0;
-    int node = MCPT_NODE_SENTINEL, sp = 1;
-#ifndef WF_NO_POSTPONE
-    // Speculative traversal (Aila & Laine 2009): a lane that reaches a leaf parks it in `pend` and keeps descending; the leaf block tests
-    // the parked leaves of all lanes at once.  Invariant at the loop head: `node` is a leaf only while `pend` is occupied.  0 = none.
-    int pend = 0;
-#define WF_PEND pend
-#define WF_POP_NODE() { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = OVF(sp - WF_LDS_STACK); }
-    // tune.pend_cap == 0 (MCPT_WF_PEND=0, a developer knob) switches the speculation off: the lane parks its leaf all the same but
-    // waits for it (node = WF_NODE_WAIT).
-#define WF_NODE_WAIT ((int)0x80000001)
-    const bool speculate = tune.pend_cap != 0u;
-#define WF_PARK_LEAF() if (pend == 0 && node < 0 && node != MCPT_NODE_SENTINEL && node != WF_NODE_WAIT) { pend = node; if (speculate) WF_POP_NODE() else node = WF_NODE_WAIT; }
-#else
-#define WF_PEND 0
-#define WF_PARK_LEAF()
-#endif
-    int htri = -1; float hu = 0, hv = 0;
-    uint32_t n_box = 0, n_tri = 0, n_spill = 0;     // n_spill: stack entries that went to the global overflow area (COUNT builds)
-#ifdef WF_SCHED_STATS
-    uint32_t x_inner = 0, x_leaf = 0, x_refill = 0, l_refill = 0;    // block executions (wave-uniform); n_box / n_tri count lane participations
-    unsigned long long t_inner = 0, t_leaf = 0, t_refill = 0, t_mark = __builtin_amdgcn_s_memtime();   // shader cycles spent in each block type
-#define WF_TICK(acc) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc += t_now - t_mark; t_mark = t_now; }
-#else
-#define WF_TICK(acc)
-#endif
-    const bool greedy = tune.policy == 1;
-
-    uint32_t watchdog = 0;                            // scheduler rounds of this wave: a logic error must end the launch, not hang the GPU
-    for (;;) {
-        if (++watchdog > (1u << 24)) { if (lane == 0) ctl->pad[0] = 1u; break; }   // (~10^3 cycles per round: seconds; a launch needs ~10^3 rounds)
-        const bool at_inner = have && node >= 0;
-#ifndef WF_NO_POSTPONE
-        const bool at_leaf = have && pend != 0;                                    // has a parked leaf (may still be descending)
-        const int n_inner = __popcll(__ballot(at_inner)), n_pend = __popcll(__ballot(at_leaf));
-        const int n_leaf = __popcll(__ballot(at_leaf && node < 0));                // ... and cannot go on without it
-        const int n_idle = 64 - n_inner - n_leaf;
-#else
-        const bool at_leaf = have && node < 0 && node != MCPT_NODE_SENTINEL;
-        const int n_inner = __popcll(__ballot(at_inner)), n_leaf = __popcll(__ballot(at_leaf));
-        const int n_idle = 64 - n_inner - n_leaf;
-#endif
-
-        const int most = n_inner > n_leaf ? n_inner : n_leaf;
-        if ((n_inner + n_leaf == 0) || (!exhausted && (greedy ? n_idle >= most : n_idle >= (int)tune.refill_at))) {
-            // ------------------------------------------------------------------ refill block
-#ifdef WF_SCHED_STATS
-            x_refill++; l_refill += (uint32_t)n_idle;
-#endif
-            if (have && node == MCPT_NODE_SENTINEL && WF_PEND == 0) {    // finished: write the result back
-                if (any) {                                               // Render.cpp:125-130: the verdict.  The next shade call adds the
-                    if (blocked) st_s(reinterpret_cast<uint32_t*>(&pool.nee[slot]) + 3, 1u);   // ... NEE term it parked in pool.nee unless .w says "blocked"
-                } else {
-                    st_s(&pool.hit[slot], make_float4(__int_as_float(htri), hu, hv, tmax));   // closest hit: tmax IS its distance
-                }
-                have = false;
-            }
-            if (!exhausted) {
-                // hand every idle lane the next ray of the list; a refill may cross chunk boundaries (shadow chunks are short)
-                const uint64_t m_idle = __ballot(!have);
-                const uint32_t rank = lane_rank(m_idle);
-                uint32_t remaining = (uint32_t)__popcll(m_idle), assigned = 0;
-                bool got = false, my_shadow = false; uint32_t my_w = 0, my_q = 0;
-                for (int pass = 0; pass < 4 && remaining > 0; pass++) {
-                    if (w_next == w_end) {                               // next chunk (uniform branch)
-                        if (c_next == c_end) {
-                            uint32_t c = 0;
-                            if (lane == 0) c = atomicAdd(head, batch);
-                            c_next = wave_first(c) + n_waves * batch; c_end = c_next + batch;
-                        }
-                        take_chunk(c_next++);
-                        if (exhausted) break;
-                    }
-                    const uint32_t take = min(w_end - w_next, remaining);
-                    if (!have && !got && rank >= assigned && rank < assigned + take) { got = true; my_w = w_next + (rank - assigned); my_shadow = chunk_shadow; my_q = q_base; }
-                    w_next += take; assigned += take; remaining -= take;
-                }
-                if (got) {
-                    bool valid;
-                    if (!my_shadow) {                                    // extend ray of slot my_w
-                        slot = my_w;
-                        const float4 rd = ld_s(&pool.ray_d[my_w]);
-                        valid = (__float_as_uint(rd.w) & 1u) != 0u;
-                        const float4 ro = ld_s(&pool.ray_o[my_w]);
-                        o = xyz(ro); d = xyz(rd); tmax = 3.0e38f; any = false; htri = -1;
-                    } else {                                             // shadow ray of a queued slot
-                        slot = ld_s(&pool.shadow_queue[my_q + my_w]);
-                        const float4 ro = ld_s(&pool.sq_o[my_q + my_w]), sd = ld_s(&pool.sq_d[my_q + my_w]);
-                        o = xyz(ro); d = xyz(sd); tmax = sd.w; any = true; htri = __float_as_int(ro.w); valid = true;   // htri: the light triangle to skip
-                    }
-                    if (valid) {
-                        const float tiny = 1e-30f;
-                        idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
-                        idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
-                        idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
-                        stk[0] = MCPT_NODE_SENTINEL; sp = 1; node = 0;
-                        hu = 0.f; hv = 0.f; blocked = false;
-                        have = true;
-                    }
-                }
-            }
-            WF_TICK(t_refill)
-            if (exhausted && __ballot(have) == 0) break;
-            continue;
-        }
-
-#ifndef WF_NO_POSTPONE
-        if (n_leaf >= (int)tune.leaf_at || n_inner == 0 || (speculate && n_pend >= (int)tune.pend_cap)) {
-#else
-        if ((greedy ? n_leaf >= n_inner : n_leaf >= (int)tune.leaf_at) || n_inner == 0) {
-#endif
-            // ------------------------------------------------------------------ leaf block (all lanes waiting at a leaf)
-#ifdef WF_SCHED_STATS
-            x_leaf++; if (at_leaf) n_tri++;
-#endif
-            if (at_leaf) {
-#ifndef WF_NO_POSTPONE
-                const uint32_t leaf = (uint32_t)~pend;
-#else
-                const uint32_t leaf = (uint32_t)~node;
-#endif
-                const uint32_t first = leaf >> 3, cnt = leaf & 7u;
-                // The stack pop is requested BEFORE the triangle records, and a leaf's triangles are handled in pairs (a leaf of the SAH
-                // builder holds at most two).  The leaf block is 27 % of the waves' time at ~3 800 cycles per execution (tools/sched_stats.py).
-#ifdef WF_NO_POSTPONE
-                const int sp1 = sp - 1;
-                int popped;
-                if (sp1 < WF_LDS_STACK) popped = stk[sp1 * WF_TRACE_BLOCK]; else popped = OVF(sp1 - WF_LDS_STACK);
-#endif
-                bool done = false;
-#pragma unroll 1
-                for (uint32_t i = 0; i < cnt && !done; i += 2) {
-                    const int ta = (int)(first + i), tb = ta + 1;
-                    const bool use_a = !(any && ta == htri), use_b = i + 1 < cnt && !(any && tb == htri);   // any-hit rays keep their `skip` triangle in htri
-                    // (Fetching both records unconditionally -- no merge with a zero-initialised value, so the compiler requests b before it
-                    // waits for a -- costs 12 more registers (72 -> 84) and is a net loss: the trace kernel alone gains nothing (535 vs 536 ms)
-                    // and beside it one shade wave fewer fits on each SIMD (501 vs 484 ms per step).  -DWF_LEAF_UNCOND builds that form.)
-                    const float4* T = sc.tri_isect + 3 * (size_t)ta;
-#ifdef WF_LEAF_UNCOND
-                    const float4 v0a = T[0], e1a = T[1], e2a = T[2], v0b = T[3], e1b = T[4], e2b = T[5];   // tri_isect has one spare record at its end
-#else
-                    float4 v0a = make_float4(0, 0, 0, 0), e1a = v0a, e2a = v0a, v0b = v0a, e1b = v0a, e2b = v0a;
-                    if (use_a) { v0a = T[0]; e1a = T[1]; e2a = T[2]; }
-                    if (use_b) { v0b = T[3]; e1b = T[4]; e2b = T[5]; }
-#endif
-#ifndef WF_SCHED_STATS
-                    if (COUNT) n_tri += (use_a ? 1u : 0u) + (use_b ? 1u : 0u);
-#endif
-                    if (use_a) {
-                        const TriTest r = tri_test(v0a, e1a, e2a, o, d);
-                        if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }                     // Triangle::isIntersect
-                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = ta | (__float_as_int(v0a.w) & ~HIT_TRI_MASK); hu = r.u; hv = r.v; }   // Triangle::hit; v0.w = lobe class << 28
-                    }
-                    if (use_b && !done) {
-                        const TriTest r = tri_test(v0b, e1b, e2b, o, d);
-                        if (any) { if (tri_accept_any(r, 1e-4f, tmax)) { blocked = true; done = true; } }
-                        else if (tri_accept_closest(r, 1e-4f, tmax)) { tmax = r.t; htri = tb | (__float_as_int(v0b.w) & ~HIT_TRI_MASK); hu = r.u; hv = r.v; }
-                    }
-                }
-#ifndef WF_NO_POSTPONE
-                pend = 0;
-                if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
-                else {
-                    if (node == WF_NODE_WAIT) WF_POP_NODE()              // (no speculation: the lane resumes where it stopped)
-                    WF_PARK_LEAF()                                       // the lane was waiting AT another leaf: park that one now
-                }
-#else
-                if (done) node = MCPT_NODE_SENTINEL;                     // any-hit: stop at the first occluder
-                else { sp = sp1; node = popped; }
-#endif
-            }
-            WF_TICK(t_leaf)
-            continue;
-        }
-
-        // ---------------------------------------------------------------------- inner-node block: one 64-B record of the 4-wide tree
-        // = four child boxes, 8-bit offsets in the node's frame.  t = q * (2^e * idir) + (origin * idir - o * idir): two FMAs per
-        // plane after one v_cvt_f32_ubyteN.  Hit children are ordered by entry distance (5-comparator network); the nearest is
-        // visited next, the others go on the stack far-to-near.  Top levels come from LDS, the rest from memory.
-        int keep = (int)tune.inner_keep;
-        const bool order_matters = __ballot(have && !any) != 0;
-        do {
-#ifdef WF_SCHED_STATS
-            x_inner++; if (have && node >= 0) n_box++;
-#endif
-            if (have && node >= 0) {
-                v4f A, B, C, D;
-                if (node < MCPT_TOP_NODES) { A = top[node]; B = top[MCPT_TOP_NODES + node]; C = top[2 * MCPT_TOP_NODES + node]; D = top[3 * MCPT_TOP_NODES + node]; }
-                else { glb_cf4* n = gnodes + 4 * (size_t)node; A = n[0]; B = n[1]; C = n[2]; D = n[3]; }
-                const uint32_t meta = __float_as_uint(A.w);
-                const float ax = __uint_as_float((meta & 0xffu) << 23) * idx, ay = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy,
-                            az = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
-                const float bx = (A.x - o.x) * idx, by = (A.y - o.y) * idy, bz = (A.z - o.z) * idz;   // (node origin - ray origin) / d: no o/d registers kept
-                // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise (and vice versa for the
-                // exit planes): selecting the packed words once per node replaces a min and a max per axis per child
-                const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
-                const uint32_t qlx = __float_as_uint(B.x), qly = __float_as_uint(B.y), qlz = __float_as_uint(B.z), qhx = __float_as_uint(B.w),
-                               qhy = __float_as_uint(C.x), qhz = __float_as_uint(C.y);
-                const uint32_t qnx = ngx ? qhx : qlx, qfx = ngx ? qlx : qhx, qny = ngy ? qhy : qly, qfy = ngy ? qly : qhy, qnz = ngz ? qhz : qlz, qfz = ngz ? qlz : qhz;
-                const uint32_t valid = meta >> 24;
-                float key0, key1, key2, key3;
-#define WF_CHILD(K, KEY)                                                                                                             \
-                {                                                                                                                    \
-                    const float t0x = fmaf((float)((qnx >> (8 * K)) & 0xffu), ax, bx), t1x = fmaf((float)((qfx >> (8 * K)) & 0xffu), ax, bx); \
-                    const float t0y = fmaf((float)((qny >> (8 * K)) & 0xffu), ay, by), t1y = fmaf((float)((qfy >> (8 * K)) & 0xffu), ay, by); \
-                    const float t0z = fmaf((float)((qnz >> (8 * K)) & 0xffu), az, bz), t1z = fmaf((float)((qfz >> (8 * K)) & 0xffu), az, bz); \
-                    const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 1e-4f));                                                      \
-                    const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));                                                       \
-                    KEY = (((valid >> K) & 1u) && tn <= tf) ? tn : __builtin_inff();                                                 \
-                }
-                WF_CHILD(0, key0) WF_CHILD(1, key1) WF_CHILD(2, key2) WF_CHILD(3, key3)
-#undef WF_CHILD
-#ifndef WF_SCHED_STATS
-                if (COUNT) n_box += (uint32_t)__popc(valid);
-#endif
-                int cd0 = __float_as_int(D.x), cd1 = __float_as_int(D.y), cd2 = __float_as_int(D.z), cd3 = __float_as_int(D.w);
-#define WF_CSWAP(KA, CA, KB, CB) { const bool sw = KB < KA; const float tk = sw ? KB : KA; KB = sw ? KA : KB; KA = tk; const int tc = sw ? CB : CA; CB = sw ? CA : CB; CA = tc; }
-                // any-hit rays (Render.cpp:125: is the light visible at all) do not care in which order the children are visited, and the ray
-                // list hands a wave long runs of one kind (all extend chunks come before all shadow chunks): while no lane of the wave
-                // carries a closest-hit ray the 5-comparator network is skipped (a wave-uniform branch)
-                if (order_matters) {
-                    WF_CSWAP(key0, cd0, key1, cd1) WF_CSWAP(key2, cd2, key3, cd3) WF_CSWAP(key0, cd0, key2, cd2) WF_CSWAP(key1, cd1, key3, cd3) WF_CSWAP(key1, cd1, key2, cd2)
-                }
-#undef WF_CSWAP
-                const float inf = __builtin_inff();
-                const int h1 = key1 < inf, h2 = key2 < inf, h3 = key3 < inf;      // (sorted: hits are a prefix; unsorted: any pattern -- the pushes below handle both)
-                if (sp + 3 <= WF_LDS_STACK) {
-                    // common case, branch-free: store all three candidates, advance the stack pointer only past real hits (a slot
-                    // written without the bump is simply overwritten later); the pop reads the slot below the new top
-                    stk[sp * WF_TRACE_BLOCK] = cd3; sp += h3;
-                    stk[sp * WF_TRACE_BLOCK] = cd2; sp += h2;
-                    stk[sp * WF_TRACE_BLOCK] = cd1; sp += h1;
-                    const int below = stk[(sp - 1) * WF_TRACE_BLOCK];
-                    const bool hit0 = key0 < inf;
-                    node = hit0 ? cd0 : below;
-                    sp -= hit0 ? 0 : 1;
-                } else {                                                   // rare: near the LDS limit -> entries may go to the overflow area
-                    if (h3) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd3; else { OVF(sp - WF_LDS_STACK) = cd3; if (COUNT) n_spill++; } sp++; }
-                    if (h2) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd2; else { OVF(sp - WF_LDS_STACK) = cd2; if (COUNT) n_spill++; } sp++; }
-                    if (h1) { if (sp < WF_LDS_STACK) stk[sp * WF_TRACE_BLOCK] = cd1; else { OVF(sp - WF_LDS_STACK) = cd1; if (COUNT) n_spill++; } sp++; }
-                    if (key0 < inf) node = cd0;
-                    else { sp--; if (sp < WF_LDS_STACK) node = stk[sp * WF_TRACE_BLOCK]; else node = OVF(sp - WF_LDS_STACK); }
-                }
-                WF_PARK_LEAF()
-#ifdef WF_DUMMY_VALU    /* regime probe: N extra VALU issues per inner step (independent of everything, results discarded) */
-                { float dz = idx;
-#pragma unroll
-                  for (int k = 0; k < WF_DUMMY_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dz));
-                  asm volatile("" :: "v"(dz)); }
-#endif
-            }
-            if (greedy) {                                                  // stay while inner nodes are still what most lanes wait for
-                const int cl = __popcll(__ballot(have && node < 0 && node != MCPT_NODE_SENTINEL)), ci = __popcll(__ballot(have && node >= 0));
-                const int cf = exhausted ? 0 : 64 - cl - ci;
-                keep = (cl > cf ? cl : cf) + 1;
-            }
-        } while (__popcll(__ballot(have && node >= 0)) >= keep);
-        WF_TICK(t_inner)
-    }
-
-    if (COUNT) {
-        unsigned long long b = n_box, t = n_tri, sx = n_spill;
-        for (int off = 32; off > 0; off >>= 1) { b += __shfl_xor(b, off, 64); t += __shfl_xor(t, off, 64); sx += __shfl_xor(sx, off, 64); }
-        if (lane == 0) {
-            DevCounters* g = gcnt + (blockIdx.x & (WF_COUNTER_REPLICAS - 1)); atomicAdd(&g->box_tests, b); atomicAdd(&g->tri_tests, t);
-            if (sx) atomicAdd(&g->stack_spills, sx);
-#ifdef WF_SCHED_STATS   // tools/sched_stats.py: the shade-side counters are re-purposed in this diagnostic build
-            atomicAdd(&g->paths, wall_clock64() - t_start);            // wave lifetime in 10-ns ticks
-            atomicAdd(&g->shaded_hits, (unsigned long long)x_inner); atomicAdd(&g->texel_fetches, (unsigned long long)x_leaf);
-            atomicAdd(&g->self_shadow_tests, (unsigned long long)x_refill); atomicAdd(&g->self_shadow_hits, (unsigned long long)l_refill);
-            atomicAdd(&g->debug[0], t_inner); atomicAdd(&g->debug[1], t_leaf); atomicAdd(&g->debug[2], t_refill);
-#endif
-        }
-    }
-}
-
-#undef OVF
-#undef WF_PEND
-#undef WF_PARK_LEAF
-#ifndef WF_NO_POSTPONE
-#undef WF_POP_NODE
-#undef WF_NODE_WAIT
-#endif
-#undef WF_TICK
-// ====================================================================================================== trace, 8-wide tree
 // BVH_node::hit / has_hit (BVH.cpp:95-136), AABB::Intersection (AABB.cpp:25-36), Triangle::hit / isIntersect (Triangle.cpp:48-106) for the
 // whole ray list of one iteration, over the 8-wide compressed tree (device_scene.h: nodes8; Ylitie, Karras & Laine 2017, re-laid for
-// gfx950).  Same three-block wave scheduler, ray list and acceptance rules as wf_trace_kernel above; what differs is the unit of traversal:
+// gfx950).  Acceptance rules: see bvh_traverse / tri_test in pt_device.h.  Block = WF_TRACE_BLOCK (1024) threads = 16 waves sharing one LDS
+// image of the top MCPT_TOP_NODES8 records + a WF8_LDS_STACK-entry per-lane stack; the host launches one block per CU (mcpt_api.cpp).
+// Persistent waves with a three-block scheduler (refill / leaf / inner, below); the unit of traversal:
 //   * one inner step = one 80-B record = EIGHT child boxes (8-bit offsets in the node's frame, two FMAs per plane after a v_cvt_f32_ubyteN),
 //     the result an 8-bit hit mask -- no entry distances, no sorting network: the children sit in octant slots (scene_build.cpp), a ray
 //     visits them in the order of slot ^ octant, which is front to back up to ties;
@@ -909,8 +551,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace_kernel(DevScene sc, P
 //     inner children of one node in 8 B, T = {triangle base, leaf hits << 24 | count planes << 8} all its pending leaf children.  One stack
 //     entry per node instead of one per child: the stack is an 8-B-per-level LDS array, WF8_LDS_STACK deep (deeper levels spill to a global
 //     overflow area), with at most two pushes and one pop per step;
-//   * speculative traversal as before: a lane parks the leaf group of a node in T and goes on with the node's inner children; the leaf group
-//     of a later node found while T is still occupied is pushed UNDER that node's inner group and parked when it is popped.
+//   * speculative traversal (Aila & Laine 2009): a lane parks the leaf group of a node in T and goes on with the node's inner children -- the
+//     leaf block tests the parked leaves of all lanes at once; the leaf group of a later node found while T is still occupied is pushed UNDER
+//     that node's inner group and parked when it is popped.
 #ifndef WF8_LDS_STACK
 #define WF8_LDS_STACK 6
 #endif
@@ -943,7 +586,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ v2u s_stack[WF8_LDS_STACK * WF_TRACE_BLOCK];
     __shared__ float4 s_top[5 * MCPT_TOP_NODES8 + 1];                  // [record][node]  (+1: MCPT_TOP_NODES8 = 0 is a legal A/B setting)
-    typedef __attribute__((address_space(3))) v2u lds_u2;              // explicit address spaces: see wf_trace_kernel
+    // explicit address spaces: with generic pointers hipcc folds `lds ? : global` into ONE flat_load (select of pointers), which is slower than
+    // either path and hides the LDS traffic from the LDS pipe -- typed pointers keep ds_read / global_load apart
+    typedef __attribute__((address_space(3))) v2u lds_u2;
     typedef __attribute__((address_space(3))) v4f lds_f4;
     typedef __attribute__((address_space(1))) v2u glb_u2;
     typedef __attribute__((address_space(1))) const v4f glb_cf4;
@@ -964,7 +609,10 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 #endif
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = pool.P;
-    // the ray list and its chunks: exactly as in wf_trace_kernel
+    // Ray list = 2 * P / 256 chunks: chunk c < P/256 holds the extend rays of slots [256 c, 256 c + 256); chunk P/256 + b holds the
+    // shadow rays shade block b queued (shadow_count[b] of them).  A wave owns one chunk at a time: the first statically (no atomic),
+    // later ones from `head`.  A list with fewer chunks than waves (a small call: one sample per pixel of a small film) is handed out in
+    // quarter chunks of 64 rays, so that every wave of the grid gets rays and no lane works four of them one after the other.
     const uint32_t n_ext_chunks = P / WF_SHADE_BLOCK;
     const uint32_t n_waves = gridDim.x * (WF_TRACE_BLOCK / 64);
     const uint32_t sub_sh = 2 * n_ext_chunks < n_waves ? 2u : 0u;
@@ -972,7 +620,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     uint32_t* head = &ctl->trace_head[it & 3];
     uint32_t w_next = 0, w_end = 0, q_base = 0;
     bool chunk_shadow = false, exhausted = false;
-    auto take_chunk = [&](uint32_t c) {
+    auto take_chunk = [&](uint32_t c) {              // (straight-line on purpose: with early returns the compiler kept w_next / w_end in scratch)
         const uint32_t cc = c >> sub_sh, part = c & ((1u << sub_sh) - 1u), span = (uint32_t)WF_SHADE_BLOCK >> sub_sh;
         const bool none = c >= n_chunks, ext = cc < n_ext_chunks, shadow = !none && !ext;
         const uint32_t b = shadow ? cc - n_ext_chunks : 0u;
@@ -985,9 +633,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         w_next = base + lo;
         w_end = base + hi;
     };
+    // chunks are reserved `batch` at a time: WF_CHUNK_BATCH when the list is long (one atomic on `head` per ~1-2 k rays per wave).  A short
+    // list (a one-sample-per-pixel call: 5 000 chunks for 3 584 waves) would leave most waves -- whole CUs, with block-major wave numbers --
+    // without a first chunk: there every wave takes n_chunks / n_waves (at least one) and wave numbers interleave across the blocks.
     const bool short_list = n_chunks < n_waves * WF_CHUNK_BATCH;
     const uint32_t batch = short_list ? max(1u, n_chunks / n_waves) : (uint32_t)WF_CHUNK_BATCH;
-    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: the chunk bookkeeping stays in SGPRs
     const uint32_t wave_id = short_list ? wave_in_block * gridDim.x + blockIdx.x : blockIdx.x * (WF_TRACE_BLOCK / 64) + wave_in_block;
     uint32_t c_next = wave_id * batch, c_end = c_next + batch;
     take_chunk(c_next++);
@@ -1020,6 +671,11 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     // One inner step in two halves: `issue` picks the next child of the group on top of the stack and requests its record, `consume` tests the
     // eight boxes and updates the stack.
     v4f R0, R1, R2, R3, R4;
+#if defined(WF_DUMMY_VMEM)
+    v4f DM[WF_DUMMY_VMEM];
+#elif defined(WF_DUMMY_LDS)
+    v4f DM[WF_DUMMY_LDS];
+#endif
     bool order_matters = true;
     uint32_t k64 = 0x64646464u; asm volatile("" : "+v"(k64));      // the fp16 exponent byte of WF8_CHILD's plane values, pinned in a VGPR (v_perm_b32 has one constant-bus operand: the selector)
     auto inner_issue = [&]() __attribute__((always_inline)) {
@@ -1030,6 +686,16 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         cur_y &= cur_y - 1u;
         if (node < MCPT_TOP_NODES8) { R0 = top[node]; R1 = top[MCPT_TOP_NODES8 + node]; R2 = top[2 * MCPT_TOP_NODES8 + node]; R3 = top[3 * MCPT_TOP_NODES8 + node]; R4 = top[4 * MCPT_TOP_NODES8 + node]; }
         else { glb_cf4* n = (glb_cf4*)((const __attribute__((address_space(1))) char*)gnodes + node * 80u); R0 = n[0]; R1 = n[1]; R2 = n[2]; R3 = n[3]; R4 = n[4]; }   // (32-bit byte offset from a uniform base: saddr + voffset addressing)
+#ifdef WF_DUMMY_VMEM    /* regime probe: N extra 16-B gathers per inner step from the record just requested (L1 hits: pure vector-memory address work) */
+        { const volatile __attribute__((address_space(1))) v4f* n = (const volatile __attribute__((address_space(1))) v4f*)((const __attribute__((address_space(1))) char*)gnodes + node * 80u);
+#pragma unroll
+          for (int k = 0; k < WF_DUMMY_VMEM; k++) DM[k] = n[k % 5]; }
+#endif
+#ifdef WF_DUMMY_LDS     /* regime probe: N extra 16-B LDS reads per inner step */
+        { const volatile lds_f4* n = (const volatile lds_f4*)top;
+#pragma unroll
+          for (int k = 0; k < WF_DUMMY_LDS; k++) DM[k] = n[(k * MCPT_TOP_NODES8 + node) % (5 * MCPT_TOP_NODES8)]; }
+#endif
     };
     auto inner_consume = [&]() __attribute__((always_inline)) {
         const uint32_t sxy = __float_as_uint(R0.w), masks = __float_as_uint(R1.w);
@@ -1076,6 +742,10 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         }
         if (t_park) { t_x = e_tn.x; t_y = tn_y; }
         WF8_PARK()
+#if defined(WF_DUMMY_VMEM) || defined(WF_DUMMY_LDS)    /* (the probes' results are only kept alive until here) */
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(DM) / sizeof(DM[0])); k++) asm volatile("" :: "v"(DM[k]));
+#endif
 #ifdef WF_DUMMY_VALU    /* regime probe: N extra VALU issues per inner step (independent of everything, results discarded) */
         { float dz = idx;
 #pragma unroll
@@ -1296,30 +966,21 @@ hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const Path
 }
 hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,
                            DevCounters* cnt, uint32_t grid_blocks, int* stack_overflow, hipStream_t stream) {
-    if (sc.n_nodes8 > 0) {                                               // the context's scene carries ONE wide tree: the 8-wide one unless MCPT_BVH_WIDTH=4 built the other
-        if (count) hipLaunchKernelGGL(wf_trace8_kernel<true>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
-        else hipLaunchKernelGGL(wf_trace8_kernel<false>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
-        return hipGetLastError();
-    }
-    if (count) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
-    else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
+    if (count) hipLaunchKernelGGL(wf_trace8_kernel<true>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
+    else hipLaunchKernelGGL(wf_trace8_kernel<false>, dim3(grid_blocks), dim3(WF_TRACE_BLOCK), 0, stream, sc, pool, ctl, iteration, tune, cnt, stack_overflow);
     return hipGetLastError();
 }
-int wf_trace_blocks_per_cu(bool count, uint32_t width) {
+int wf_trace_blocks_per_cu(bool count) {
     int n = 0;
-    hipError_t e;
-    if (width == 8) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace8_kernel<true>, WF_TRACE_BLOCK, 0)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace8_kernel<false>, WF_TRACE_BLOCK, 0);
-    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, WF_TRACE_BLOCK, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<false>, WF_TRACE_BLOCK, 0);
+    const hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace8_kernel<true>, WF_TRACE_BLOCK, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace8_kernel<false>, WF_TRACE_BLOCK, 0);
     if (e != hipSuccess || n <= 0) n = 1;
     return n;
 }
 uint32_t wf_trace_block_threads() { return WF_TRACE_BLOCK; }
-// Bytes of the global stack-overflow area per trace lane.  4-wide tree: one 4-B entry per deferred child, 3 per level worst case.  8-wide
-// tree: one 8-B group per level for the pending siblings plus one for a leaf group found while another is parked.
-size_t wf_trace_overflow_bytes_per_lane(uint32_t depth, uint32_t width) {
-    if (width == 8) { const uint32_t need = 2 * depth + 3; return size_t(need > WF8_LDS_STACK ? need - WF8_LDS_STACK : 1) * 8; }
-    const uint32_t need = 3 * depth + 4;
-    return size_t(need > WF_LDS_STACK ? need - WF_LDS_STACK : 1) * 4;
+// Bytes of the global stack-overflow area per trace lane: one 8-B group per level for the pending siblings plus one for a leaf group found
+// while another is parked.
+size_t wf_trace_overflow_bytes_per_lane(uint32_t depth) {
+    const uint32_t need = 2 * depth + 3;
+    return size_t(need > WF8_LDS_STACK ? need - WF8_LDS_STACK : 1) * 8;
 }

@@ -114,23 +114,47 @@ bool load_png(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
     }
     return true;
 }
-// ---- BMP (BITMAPINFOHEADER and later, uncompressed): 8-bit palettised, 24- and 32-bit true colour; bottom-up or top-down rows
+// ---- BMP (BITMAPINFOHEADER and later): 8-bit palettised (uncompressed or RLE8), 24- and 32-bit true colour; bottom-up or top-down rows.
+//      Every header field is checked against the file size BEFORE it is used as an offset or a count (a crafted biClrUsed < 0 or a huge
+//      header size used to put the palette outside the buffer: ASan repro in tools/fuzz_loader.py's header mutations).
 bool load_bmp(const std::vector<unsigned char>& f, int& w, int& h, std::vector<unsigned char>& rgb) {
     auto le16 = [&](size_t p) { return int(f[p]) | (int(f[p + 1]) << 8); };
     auto le32 = [&](size_t p) { return int32_t(uint32_t(f[p]) | (uint32_t(f[p + 1]) << 8) | (uint32_t(f[p + 2]) << 16) | (uint32_t(f[p + 3]) << 24)); };
     if (f.size() < 54 || f[0] != 'B' || f[1] != 'M') return false;
     const size_t off = size_t(uint32_t(le32(10))); const int hdr = le32(14);
-    if (hdr < 40) return false;
+    if (hdr < 40 || size_t(hdr) > f.size() - 14 || off > f.size()) return false;
     w = le32(18); int hh = le32(22); const int planes = le16(26), bpp = le16(28), comp = le32(30);
     const bool top_down = hh < 0; h = top_down ? -hh : hh;
-    if (w <= 0 || h <= 0 || planes != 1 || (comp != 0 && !(comp == 3 && bpp == 32)) || (bpp != 8 && bpp != 24 && bpp != 32) || size_t(w) * size_t(h) > (size_t(1) << 28)) return false;
+    const bool rle8 = comp == 1 && bpp == 8;
+    if (w <= 0 || h <= 0 || planes != 1 || (comp != 0 && !(comp == 3 && bpp == 32) && !rle8) || (bpp != 8 && bpp != 24 && bpp != 32) || size_t(w) * size_t(h) > (size_t(1) << 28)) return false;
+    if (rle8 && top_down) return false;                                  // (the format forbids it)
     const size_t stride = ((size_t(w) * bpp + 31) / 32) * 4;
-    if (off + stride * size_t(h) > f.size()) return false;
+    if (!rle8 && stride * size_t(h) > f.size() - off) return false;
     const size_t pal = 14 + size_t(hdr); int ncol = le32(46); if (ncol == 0) ncol = 256;
-    if (bpp == 8 && pal + 4 * size_t(ncol) > f.size()) return false;
+    if (bpp == 8 && (ncol < 0 || ncol > 256 || size_t(ncol) > (f.size() - pal) / 4)) return false;
+    std::vector<unsigned char> idx;                                       // RLE8: the decoded index plane, bottom-up like the file
+    if (rle8) {
+        idx.assign(size_t(w) * h, 0);
+        size_t pos = off; int x = 0, y = 0;
+        for (bool end = false; !end;) {
+            if (pos + 2 > f.size()) return false;
+            const int n = f[pos], v = f[pos + 1]; pos += 2;
+            if (n > 0) { for (int i = 0; i < n; i++) { if (x < w && y < h) idx[size_t(y) * w + x] = (unsigned char)v; x++; } }
+            else if (v == 0) { x = 0; y++; }                               // end of line
+            else if (v == 1) end = true;                                   // end of bitmap
+            else if (v == 2) { if (pos + 2 > f.size()) return false; x += f[pos]; y += f[pos + 1]; pos += 2; }   // delta
+            else {                                                         // absolute run of v indices, padded to 16 bits
+                if (pos + size_t(v) + (v & 1) > f.size()) return false;
+                for (int i = 0; i < v; i++) { if (x < w && y < h) idx[size_t(y) * w + x] = f[pos + i]; x++; }
+                pos += size_t(v) + (v & 1);
+            }
+            if (y >= h && !end) { if (pos + 2 <= f.size() && f[pos] == 0 && f[pos + 1] == 1) end = true; else if (y > h) return false; }
+        }
+    }
     rgb.resize(size_t(w) * h * 3);
     for (int y = 0; y < h; y++) {
-        const unsigned char* row = &f[off + stride * size_t(top_down ? y : h - 1 - y)];
+        const size_t src_row = size_t(top_down ? y : h - 1 - y);
+        const unsigned char* row = rle8 ? &idx[src_row * w] : &f[off + stride * src_row];
         for (int x = 0; x < w; x++) {
             unsigned char* o = &rgb[3 * (size_t(y) * w + x)];
             if (bpp == 8) { const int i = row[x] < ncol ? row[x] : 0; const unsigned char* p = &f[pal + 4 * size_t(i)]; o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; }
@@ -139,18 +163,25 @@ bool load_bmp(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
     }
     return true;
 }
-// ---- TGA: true colour (types 2 / 10, 24 or 32 bits) and grey (3 / 11, 8 bits), raw or run-length coded, either vertical orientation.
-//      No signature exists for this format: tried last, and only for a plausible header.
+// ---- TGA: true colour (types 2 / 10; 24 or 32 bits), grey (3 / 11; 8 bits) and colour-mapped (1 / 9; 8-bit indices into a 24- or 32-bit
+//      map), raw or run-length coded, either orientation.  No signature exists for this format: tried last, only for a plausible header,
+//      and nothing is allocated before the pixel count has been checked against the 2^28 cap and against what the file can hold.
 bool load_tga(const std::vector<unsigned char>& f, int& w, int& h, std::vector<unsigned char>& rgb) {
     if (f.size() < 18) return false;
     const int idlen = f[0], cmap = f[1], type = f[2], bpp = f[16], desc = f[17];
+    const int cm_first = int(f[3]) | (int(f[4]) << 8), cm_len = int(f[5]) | (int(f[6]) << 8), cm_bits = f[7];
     w = int(f[12]) | (int(f[13]) << 8); h = int(f[14]) | (int(f[15]) << 8);
-    const bool grey = type == 3 || type == 11, rle = type == 10 || type == 11;
-    if (cmap != 0 || !(type == 2 || type == 3 || type == 10 || type == 11) || w <= 0 || h <= 0 || (grey ? bpp != 8 : (bpp != 24 && bpp != 32)) || (desc & 0xC0)) return false;
+    const bool grey = type == 3 || type == 11, mapped = type == 1 || type == 9, rle = type == 9 || type == 10 || type == 11;
+    if (!(type == 1 || type == 2 || type == 3 || type == 9 || type == 10 || type == 11) || w <= 0 || h <= 0 || (desc & 0xC0)) return false;
+    if (mapped ? (cmap != 1 || bpp != 8 || (cm_bits != 24 && cm_bits != 32) || cm_len == 0) : (cmap != 0 || (grey ? bpp != 8 : (bpp != 24 && bpp != 32)))) return false;
     const size_t px = size_t(bpp / 8), n = size_t(w) * h;
+    if (n > (size_t(1) << 28)) return false;
+    const size_t cm_px = size_t(cm_bits / 8), cm_at = 18 + size_t(idlen), cm_bytes = mapped ? size_t(cm_len) * cm_px : 0;
+    size_t pos = cm_at + cm_bytes, o = 0;
+    if (pos > f.size()) return false;
+    if (rle ? n * px > 128 * px * (f.size() - pos) : n * px > f.size() - pos) return false;   // more pixels than the rest of the file can code
     std::vector<unsigned char> raw(n * px);
-    size_t pos = 18 + size_t(idlen), o = 0;
-    if (!rle) { if (pos + raw.size() > f.size()) return false; std::memcpy(raw.data(), &f[pos], raw.size()); }
+    if (!rle) std::memcpy(raw.data(), &f[pos], raw.size());
     else while (o < raw.size()) {
         if (pos >= f.size()) return false;
         const int c = f[pos++]; const size_t cnt = size_t(c & 127) + 1;
@@ -164,7 +195,9 @@ bool load_tga(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
         for (int x = 0; x < w; x++) {
             const unsigned char* p = &raw[(size_t(top_down ? y : h - 1 - y) * w + size_t(right_left ? w - 1 - x : x)) * px];
             unsigned char* q = &rgb[3 * (size_t(y) * w + x)];
-            if (grey) q[0] = q[1] = q[2] = p[0]; else { q[0] = p[2]; q[1] = p[1]; q[2] = p[0]; }
+            if (mapped) { const int i = int(p[0]) - cm_first; const unsigned char* m = &f[cm_at + cm_px * size_t(i >= 0 && i < cm_len ? i : 0)]; q[0] = m[2]; q[1] = m[1]; q[2] = m[0]; }
+            else if (grey) q[0] = q[1] = q[2] = p[0];
+            else { q[0] = p[2]; q[1] = p[1]; q[2] = p[0]; }
         }
     return true;
 }
@@ -185,17 +218,85 @@ bool load_ppm(const std::vector<unsigned char>& f, int& w, int& h, std::vector<u
     rgb.assign(f.begin() + pos, f.begin() + pos + size_t(w) * h * 3);
     return true;
 }
+// ---- Radiance RGBE (.hdr): the one input stbi_loadf returns LINEAR (model.cpp:11; every LDR format goes through (c/255)^2.2).  Header
+//      "#?RADIANCE" or "#?RGBE", a FORMAT=32-bit_rle_rgbe line, a blank line, "-Y h +X w"; scanlines either flat RGBE quadruples or --
+//      for 8 <= w < 32768 -- the "new" run-length form (2, 2, w >> 8, w & 255, then four component planes of runs / dumps).  A texel is
+//      mantissa * 2^(e - 136), or 0 where e == 0.  Like stb, a file whose first scanline does not start with the RLE marker is read as flat
+//      quadruples from that point on.
+bool load_hdr(const std::vector<unsigned char>& f, int& w, int& h, std::vector<float>& rgbf) {
+    size_t pos = 0;
+    auto line = [&](std::string& out) { out.clear(); while (pos < f.size() && f[pos] != '\n') { if (out.size() < 1023) out.push_back(char(f[pos])); pos++; } if (pos < f.size()) pos++; return true; };
+    std::string ln;
+    line(ln);
+    if (ln != "#?RADIANCE" && ln != "#?RGBE") return false;
+    bool fmt = false;
+    for (;;) { if (pos >= f.size()) return false; line(ln); if (ln.empty()) break; if (ln == "FORMAT=32-bit_rle_rgbe") fmt = true; }
+    if (!fmt) return false;
+    line(ln);
+    if (ln.compare(0, 3, "-Y ") != 0) return false;
+    char* e = nullptr; const long hh = std::strtol(ln.c_str() + 3, &e, 10);
+    while (*e == ' ') e++;
+    if (std::strncmp(e, "+X ", 3) != 0) return false;
+    const long ww = std::strtol(e + 3, nullptr, 10);
+    if (ww <= 0 || hh <= 0 || ww > (1 << 24) || hh > (1 << 24) || size_t(ww) * size_t(hh) > (size_t(1) << 28)) return false;
+    w = int(ww); h = int(hh);
+    if (size_t(w) * h > (f.size() - pos) * 128) return false;            // more texels than the rest of the file can code
+    rgbf.assign(size_t(w) * h * 3, 0.0f);
+    auto put = [&](size_t texel, const unsigned char* q) {
+        if (q[3] == 0) return;
+        const float s = std::ldexp(1.0f, int(q[3]) - 136);
+        rgbf[3 * texel] = q[0] * s; rgbf[3 * texel + 1] = q[1] * s; rgbf[3 * texel + 2] = q[2] * s;
+    };
+    auto flat_from = [&](size_t texel) {                                  // the rest of the image as plain quadruples
+        for (; texel < size_t(w) * h; texel++) { if (pos + 4 > f.size()) return false; put(texel, &f[pos]); pos += 4; }
+        return true;
+    };
+    if (w < 8 || w >= 32768) return flat_from(0);
+    std::vector<unsigned char> scan(size_t(w) * 4);
+    for (int y = 0; y < h; y++) {
+        if (pos + 4 > f.size()) return false;
+        if (f[pos] != 2 || f[pos + 1] != 2 || (f[pos + 2] & 0x80)) {
+            // not run-length coded: stb takes these four bytes as texel 0 and reads everything after them as flat data (whatever the row)
+            std::fill(rgbf.begin(), rgbf.end(), 0.0f);
+            put(0, &f[pos]); pos += 4;
+            return flat_from(1);
+        }
+        if (((int(f[pos + 2]) << 8) | f[pos + 3]) != w) return false;
+        pos += 4;
+        for (int k = 0; k < 4; k++)
+            for (int x = 0; x < w;) {
+                if (pos >= f.size()) return false;
+                int cnt = f[pos++];
+                if (cnt > 128) { cnt -= 128; if (cnt > w - x || pos >= f.size()) return false; const unsigned char v = f[pos++]; for (int z = 0; z < cnt; z++) scan[size_t(x++) * 4 + k] = v; }
+                else { if (cnt == 0 || cnt > w - x || pos + size_t(cnt) > f.size()) return false; for (int z = 0; z < cnt; z++) scan[size_t(x++) * 4 + k] = f[pos++]; }
+            }
+        for (int x = 0; x < w; x++) put(size_t(y) * w + x, &scan[size_t(x) * 4]);
+    }
+    return true;
+}
 }  // namespace
 
 bool load_image_rgb8(const std::string& filename, int& w, int& h, std::vector<unsigned char>& rgb) {
     const std::vector<unsigned char> bytes = read_file<std::vector<unsigned char>>(filename);
     return !bytes.empty() && (load_png(bytes, w, h, rgb) || load_jpeg(bytes, w, h, rgb) || load_ppm(bytes, w, h, rgb) || load_bmp(bytes, w, h, rgb) || load_tga(bytes, w, h, rgb));
 }
+bool load_image_hdr(const std::string& filename, int& w, int& h, std::vector<float>& rgbf) {
+    const std::vector<unsigned char> bytes = read_file<std::vector<unsigned char>>(filename);
+    return !bytes.empty() && load_hdr(bytes, w, h, rgbf);
+}
 
 Texture::Texture(const std::string& filename) {
     std::vector<unsigned char> rgb; int w = 0, h = 0;
+    {   // Radiance .hdr: stbi_loadf hands its floats over as they are -- linear, no gamma (stb_image.h: stbi__loadf_main -> stbi__hdr_load)
+        std::vector<float> lin;
+        if (load_image_hdr(filename, w, h, lin)) {
+            image_w = w; image_h = h; image_color.resize(size_t(w) * h);
+            for (size_t i = 0; i < image_color.size(); i++) { image_color[i].x = lin[3 * i]; image_color[i].y = lin[3 * i + 1]; image_color[i].z = lin[3 * i + 2]; }
+            return;
+        }
+    }
     if (!load_image_rgb8(filename, w, h, rgb)) {
-        std::cerr << "Error: cannot decode texture (PNG, JPEG, binary PPM, uncompressed BMP or true-colour / grey TGA expected): " << filename << std::endl;
+        std::cerr << "Error: cannot decode texture (PNG, JPEG, binary PPM, BMP, TGA or Radiance HDR expected): " << filename << std::endl;
         ok = false; image_color.push_back(Color3f{0.5f, 0.5f, 0.5f}); return;
     }
     image_w = w; image_h = h;

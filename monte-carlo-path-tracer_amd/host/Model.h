@@ -13,12 +13,14 @@ struct dvec2 { double x = 0, y = 0; };
 struct Color3f { float x = 0, y = 0, z = 0; };
 typedef std::array<std::array<int, 4>, 3> imat3x4;   // per corner {v_idx, vn_idx, vt_idx, material_idx} (model.h:57)
 
-// 8-bit RGB pixels of a PNG (non-interlaced, 8 bit), baseline JPEG or binary PPM file, row 0 = top of the image
+// 8-bit RGB pixels of a PNG, JPEG, binary PPM, BMP or TGA file, row 0 = top of the image
 bool load_image_rgb8(const std::string& filename, int& w, int& h, std::vector<unsigned char>& rgb);
+// linear float RGB texels of a Radiance RGBE (.hdr) file, row 0 = top of the image
+bool load_image_hdr(const std::string& filename, int& w, int& h, std::vector<float>& rgbf);
 
 class Texture {                                       // model.h:21-30
 public:
-    explicit Texture(const std::string& filename);   // 8-bit PNG (non-interlaced) or binary PPM; texels -> (c/255)^2.2 like stbi_loadf
+    explicit Texture(const std::string& filename);   // LDR formats: texels -> (c/255)^2.2 like stbi_loadf; Radiance .hdr: linear, as stbi_loadf returns it
     explicit Texture(Color3f c);                      // constant Kd
     std::vector<Color3f> image_color;
     int image_w = 1, image_h = 1;

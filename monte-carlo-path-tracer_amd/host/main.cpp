@@ -19,7 +19,7 @@
 static void usage() {
     std::cout << "usage: mcpt_cli scene.obj [--spp N] [--batch B] [--depth D] [--gpus G] [--shard samples|tiles] [--out prefix] [--seed S] [--recursive] [--corrected]\n"
                  "                          [--deterministic] [--ref-index-order] [--ref-tie-order] [--gpu-bvh] [--check] [--dump-model file] [--save-every K]\n"
-                 "       mcpt_cli --decode-image texture.(png|jpg|ppm) out.ppm\n";
+                 "       mcpt_cli --decode-image texture.(png|jpg|ppm|bmp|tga|hdr) out.(ppm|pfm)\n";
 }
 
 int main(int argc, char** argv) {
@@ -27,6 +27,15 @@ int main(int argc, char** argv) {
     if (std::string(argv[1]) == "--decode-image") {              // host-only helper: texture file -> binary PPM (what map_Kd textures decode to)
         if (argc != 4) { usage(); return 2; }
         int w = 0, h = 0; std::vector<unsigned char> rgb;
+        {   // a Radiance .hdr decodes to linear floats: written as a binary PFM-like dump ("PF\nw h\n-1.0\n" + w*h*3 little-endian floats, top row first)
+            std::vector<float> lin;
+            if (load_image_hdr(argv[2], w, h, lin)) {
+                FILE* f = std::fopen(argv[3], "wb");
+                if (!f) return 1;
+                std::fprintf(f, "PF\n%d %d\n-1.0\n", w, h); std::fwrite(lin.data(), 4, lin.size(), f); std::fclose(f);
+                return 0;
+            }
+        }
         if (!load_image_rgb8(argv[2], w, h, rgb)) { std::cerr << "Error: cannot decode " << argv[2] << std::endl; return 1; }
         FILE* f = std::fopen(argv[3], "wb");
         if (!f) return 1;

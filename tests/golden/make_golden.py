@@ -18,7 +18,8 @@ Files:
                        paths, BVH::hit / has_hit ray records, light samples, and default-mode mean / variance images
                        (`python tests/golden/make_golden.py scenes2` writes only this file)
   ref_fullsize_<c>.npz (round 3) 8x8-block mean / variance-of-the-mean maps of the real reference at the bench configurations' own sizes
-                       (c2: S-cornell 800x800 depth 8; c3: S-veach 1280x720; c4s: S-bath 93 k triangles 1920x1080), 128 spp each
+                       (c2: S-cornell 800x800 depth 8; c3: S-veach 1280x720; c4s: S-bath 93 k triangles 1920x1080), 128 spp each;
+                       round 4: c4 = S-bath 0.59 M triangles 1920x1080 and c5w = the 4.05 M-triangle S-bath, depth 16, 480x270 film, 64 spp each
                        (`... make_golden.py fullsize c2` etc.: one configuration per process, tens of CPU-minutes each)
   ref_ties.npz         (round 3) BVH::hit of the real reference on rays into eight coincident floors: which face wins an exact tie
                        (`... make_golden.py ties`)
@@ -194,6 +195,9 @@ FULLSIZE = {   # tag: (generator, kwargs, (w, h), depth limit (0 = the reference
     "c2": ("cornell-box", {}, (800, 800), 8, 8, 16),
     "c3": ("veach-mis", {}, (1280, 720), 0, 8, 16),
     "c4s": ("bathroom2", {"detail": 64}, (1920, 1080), 0, 8, 16),
+    # round 4: the two large configurations with their REAL triangle counts (the reference's regex OBJ parser takes minutes on these: paid once, here)
+    "c4": ("bathroom2", {"detail": 160}, (1920, 1080), 0, 8, 8),          # BASELINE configs[3]: 0.59 M triangles, 64 spp
+    "c5w": ("bathroom2", {"detail": 420}, (480, 270), 16, 8, 8),          # BASELINE configs[4]'s 4.05 M-triangle scene, depth 16, through a 480x270 film of the same view
 }
 
 
@@ -334,7 +338,7 @@ def main():
         scenes2(); return
     if len(sys.argv) > 1 and sys.argv[1] == "loader":
         loader(); return
-    if len(sys.argv) > 2 and sys.argv[1] == "fullsize":                    # one configuration per process (tens of CPU-minutes each): c2 | c3 | c4s
+    if len(sys.argv) > 2 and sys.argv[1] == "fullsize":                    # one configuration per process (tens of CPU-minutes each): c2 | c3 | c4s | c4 | c5w
         fullsize(sys.argv[2]); return
     scene = pkg.scenes.cornell_box_small(64, 64)
     tmp = tempfile.mkdtemp(prefix="mcpt_golden_")

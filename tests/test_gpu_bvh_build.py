@@ -1,10 +1,10 @@
 """-m gpu: the device BVH builder (csrc/bvh_gpu.hip, MCPT_FLAG_GPU_BVH_BUILD) behind the same C ABI.
 
 The traversal result does not depend on the tree (closest hit = min t, any hit = exists), so a device-built tree must
-  (a) pass the host-side soundness walk of the quantised 4-wide tree (MCPT_VALIDATE_BVH=1: every triangle referenced once and
+  (a) pass the host-side soundness walk of the quantised 8-wide tree (MCPT_VALIDATE_BVH=1: every triangle referenced once and
       inside every box on its root path),
   (b) return the reference's own hits on the reference's own random rays (tests/golden/ref_paths.npz), through both the binary
-      tree (probe kernels) and the 4-wide tree (render),
+      tree (probe kernels) and the 8-wide tree (render),
   (c) render the image the host-built tree renders, sample for sample (deterministic mode), up to exact-tie pixels."""
 import os
 

@@ -311,7 +311,7 @@ def _trace4_vs_reference(r, p):
 @pytest.mark.parametrize("tree", ["host-sah", "device-lbvh"])
 @pytest.mark.parametrize("grid", [0, 1])
 def test_probe_trace4_hot_kernel_vs_reference(pkg, paths, tree, grid):
-    """The PRODUCTION traversal (wf_trace_kernel: 4-wide quantised nodes, LDS top levels, LDS + overflow stack, chunked ray list)
+    """The PRODUCTION traversal (wf_trace8_kernel: 8-wide compressed nodes, LDS top levels, LDS + overflow group stack, chunked ray list)
     on the reference's own 4 000 rays: BVH::hit (same triangle, same t) and BVH::has_hit (same verdict with the reference's t2) on
     >= 99.9 % of rays -- with the host SAH tree and the device-built LBVH, on the full persistent grid and on ONE block
     (MCPT_WF_GRID=1: every chunk of the ray list comes from the atomic cursor)."""
@@ -663,8 +663,8 @@ def test_full_size_properties_other_configs(pkg, name, kw, res, depth):
 # ------------------------------------------------------------------------------------------------ configs[4] (C5): the HBM-bound case
 @pytest.fixture(scope="module")
 def c5_scene(pkg):
-    """S-bath stress at BASELINE.json configs[4] size: 3840x2160, 4.05 M triangles (2.75 GB of scene on the device: 4-wide nodes +
-    triangle records = 330 MB, beyond L2 and the 256 MB Infinity Cache -> the trace kernel takes its whole-chip grid)."""
+    """S-bath stress at BASELINE.json configs[4] size: 3840x2160, 4.05 M triangles (2.6 GB of scene on the device: 8-wide nodes +
+    triangle records = 229 MB, beyond L2 and the 256 MB Infinity Cache -> the trace kernel takes its whole-chip grid)."""
     return pkg.scenes.bathroom_stress(3840, 2160, detail=420)
 
 
@@ -711,14 +711,14 @@ def test_c5_same_seed_vs_oracle_small_view(pkg, orc, c5_scene):
 
 
 def test_c5_device_built_tree_same_seed_vs_oracle(pkg, orc, c5_scene):
-    """The 4 M-triangle scene with the tree built ON THE DEVICE (PLOC over the Morton order + level-synchronous 4-wide collapse and
+    """The 4 M-triangle scene with the tree built ON THE DEVICE (PLOC over the Morton order + level-synchronous 8-wide collapse and
     quantisation, MCPT_FLAG_GPU_BVH_BUILD): the binary tree comes out deeper than the cross-check kernels' 64-entry stack (69 levels),
-    which a wavefront-only context accepts -- the production kernel walks the 4-wide collapse (31 levels, stack sized from it) -- while
+    which a wavefront-only context accepts -- the production kernel walks the 8-wide collapse (stack sized from its depth) -- while
     mcpt_probe_trace, which would walk the binary tree, refuses.  Same seed against the fp64 oracle through a 64x36 film."""
     scene = c5_scene.with_resolution(64, 36)
     flags = pkg.FLAG_CORRECT_SHADOW_T2
     spp = 8
-    os.environ["MCPT_VALIDATE_BVH"] = "1"                                  # host-side soundness walk of the device-made 4-wide tree
+    os.environ["MCPT_VALIDATE_BVH"] = "1"                                  # host-side soundness walk of the device-made 8-wide tree
     try:
         r = pkg.Renderer(scene, max_depth=16, flags=flags | pkg.FLAG_GPU_BVH_BUILD | pkg.FLAG_COUNT_TRAVERSAL)
     finally:

@@ -29,7 +29,7 @@ def test_loader_survives_mutated_scenes(tmp_path):
 @pytest.mark.skipif(shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"), reason="needs g++ and the HIP headers")
 def test_scene_builder_survives_hostile_descriptions(tmp_path):
     """tools/fuzz_scene_build.cpp under ASan + UBSan: NaN / inf / huge coordinates, indices out of range, degenerate geometry,
-    zero-sized films and textures.  Rejected or accepted, never a crash or a hang; an accepted scene's 4-wide tree must be sound."""
+    zero-sized films and textures.  Rejected or accepted, never a crash or a hang; an accepted scene's 8-wide tree must be sound."""
     import subprocess
     env = dict(os.environ, TMPDIR=str(tmp_path))
     p = subprocess.run([os.path.join(ROOT, "tools", "fuzz_scene_build.sh"), "40", "9"], capture_output=True, text=True, timeout=600, env=env)

@@ -13,4 +13,4 @@ for name, x, y in (("4+4 vs 8", ab, whole), ("8 vs 8 again", whole, whole2)):
     bad = ~np.isclose(x, y, rtol=1e-4, atol=1e-4)
     px = np.any(bad, axis=-1)
     d = np.abs(x - y)[..., :3].max(-1)
-    print(os.environ.get("MCPT_BVH_WIDTH", "8"), os.environ.get("MCPT_NO_RECENTRE", "-"), name, "pixels beyond tolerance:", int(px.sum()), " max abs diff %.4g" % d.max(), " at", np.unravel_index(d.argmax(), d.shape), x[np.unravel_index(d.argmax(), d.shape)], y[np.unravel_index(d.argmax(), d.shape)])
+    print(os.environ.get("MCPT_NO_RECENTRE", "-"), name, "pixels beyond tolerance:", int(px.sum()), " max abs diff %.4g" % d.max(), " at", np.unravel_index(d.argmax(), d.shape), x[np.unravel_index(d.argmax(), d.shape)], y[np.unravel_index(d.argmax(), d.shape)])

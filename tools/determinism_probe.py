@@ -15,4 +15,4 @@ for k in range(3):
 for k in (1, 2):
     d = np.any(imgs[0] != imgs[k], axis=-1)
     rel = np.abs(imgs[0][..., :3] - imgs[k][..., :3]).max(-1) / np.maximum(1e-3, np.abs(imgs[0][..., :3]).max(-1))
-    print("width", os.environ.get("MCPT_BVH_WIDTH", "8"), "pend", os.environ.get("MCPT_WF_PEND"), "run 0 vs", k, "pixels differing: %d of %d" % (d.sum(), d.size), " rel > 1e-3: %d  max rel %.3g" % ((rel > 1e-3).sum(), rel.max()))
+    print("pend", os.environ.get("MCPT_WF_PEND"), "run 0 vs", k, "pixels differing: %d of %d" % (d.sum(), d.size), " rel > 1e-3: %d  max rel %.3g" % ((rel > 1e-3).sum(), rel.max()))

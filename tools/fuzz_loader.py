@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Sanitizer fuzz of the host loader (OBJ / MTL / XML text; PNG incl. Adam7, baseline and progressive JPEG, BMP, TGA textures).
+"""Sanitizer fuzz of the host loader (OBJ / MTL / XML text; PNG incl. Adam7, baseline and progressive JPEG, BMP incl. palettised and RLE8,
+TGA incl. colour-mapped, Radiance RGBE textures).
 
 Builds host/Model.cpp + host/Jpeg.cpp with -fsanitize=address,undefined (CPU only; the GPU pool has no
 sanitizer runs), then feeds it mutated copies of tests/golden/loader_quirks/*: truncations, byte
-flips, deletions, spliced garbage, shuffled lines.  A finding is any sanitizer report, a crash, or a
-hang.  The loader may reject a file (ok=0) but must not read or write out of bounds.
+flips, deletions, spliced garbage, shuffled lines and -- for the binary containers -- HEADER-FIELD mutations: a 16- or 32-bit
+little-endian field in the first 64 bytes overwritten with a boundary value (0, -1, -25000, 65535, 100000, INT_MAX, INT_MIN ...), which
+is what random byte flips almost never produce (the r03 advisor's BMP finding: biClrUsed < 0 with a huge header size).  A finding is any
+sanitizer report, a crash, or a hang.  The loader may reject a file (ok=0) but must not read or write out of bounds.
 
     python tools/fuzz_loader.py [--cases N] [--seed S]
 """
@@ -45,9 +48,20 @@ def build(workdir):
     return exe
 
 
+BOUNDARY = [0, 1, -1, -2, -25000, 255, 256, 32767, 32768, 65535, 65536, 100000, 0x7fffffff, -0x80000000, 0x10000000]
+
+
 def mutate(data, rng, text):
     d = bytearray(data)
-    mode = rng.randrange(4)
+    mode = rng.randrange(4) if text else rng.randrange(6)
+    if mode >= 4 and len(d) >= 8:                                          # header-field mutation (binary containers)
+        for _ in range(rng.randint(1, 3)):
+            at = rng.randrange(0, min(len(d), 64) - 3)
+            v = rng.choice(BOUNDARY)
+            if rng.random() < 0.5: d[at:at + 4] = (v & 0xffffffff).to_bytes(4, "little")
+            else: d[at:at + 2] = (v & 0xffff).to_bytes(2, "little")
+        return bytes(d)
+    mode %= 4
     if mode == 0:
         d = d[: rng.randint(1, max(1, len(d) - 1))]
     elif mode == 1:
@@ -77,7 +91,9 @@ def run(cases, seed, workdir=None, verbose=True):
         # (model stem, file to corrupt, is text)
         targets = [("quirk", "quirk.obj", True), ("quirk", "quirk.mtl", True), ("quirk", "quirk.xml", True),
                    ("quirk", "tex.png", False), ("jpeg", "tex.jpg", False), ("order", "order.obj", True), ("order", "order.mtl", True),
-                   ("formats", "tex_prog.jpg", False), ("formats", "tex_i.png", False), ("formats", "tex.bmp", False), ("formats", "tex.tga", False)]
+                   ("formats", "tex_prog.jpg", False), ("formats", "tex_i.png", False), ("formats", "tex.bmp", False), ("formats", "tex.tga", False),
+                   ("formats2", "tex8.bmp", False), ("formats2", "tex_rle.bmp", False), ("formats2", "tex_map.tga", False), ("formats2", "tex_map_rle.tga", False),
+                   ("formats2", "tex.hdr", False)]
         scene = os.path.join(workdir, "scene")
         for k in range(cases):
             stem, victim, text = targets[k % len(targets)]

@@ -1,8 +1,8 @@
 // Sanitizer harness for the host half of mcpt_scene_create: build_host_scene (validation, flattening, light
-// collection, binned-SAH builder, 4-wide collapse + quantisation) and validate_bvh4, fed with hostile scene
+// collection, binned-SAH builder, 8-wide collapse + quantisation) and validate_wide_bvh, fed with hostile scene
 // descriptions -- indices out of range, NaN / inf / huge coordinates, degenerate and duplicated triangles, zero-sized
 // films and textures, no lights.  A description may be rejected (status != MCPT_OK); an accepted one must yield a
-// tree validate_bvh4 calls sound.  Built by tools/fuzz_scene_build.sh with -fsanitize=address,undefined (CPU only).
+// tree validate_wide_bvh calls sound.  Built by tools/fuzz_scene_build.sh with -fsanitize=address,undefined (CPU only).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

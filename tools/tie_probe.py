@@ -11,4 +11,4 @@ for spp in (16, 64):
     a, b = imgs
     differ = np.any(a[..., :3] != b[..., :3], axis=-1)
     rel = np.abs(a[..., :3] - b[..., :3]).max(-1) / np.maximum(1e-6, np.abs(a[..., :3]).max(-1))
-    print(os.environ.get("MCPT_NO_RECENTRE"), os.environ.get("MCPT_BVH_WIDTH"), "spp", spp, "differ %.4f" % differ.mean(), "rel>1e-3: %.4f" % (rel > 1e-3).mean(), "mean", a[..., :3].mean(), b[..., :3].mean())
+    print(os.environ.get("MCPT_NO_RECENTRE"), "spp", spp, "differ %.4f" % differ.mean(), "rel>1e-3: %.4f" % (rel > 1e-3).mean(), "mean", a[..., :3].mean(), b[..., :3].mean())

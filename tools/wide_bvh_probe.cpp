@@ -1,6 +1,6 @@
 // Host-only what-if: how many traversal steps per ray would a k-wide tree need?  Builds the production binary SAH tree (scene_build.cpp)
 // for an OBJ scene, collapses it to k = 2, 4, 6, 8 children per node with the production rule (adopt the children of the largest inner
-// child until the node is full) and walks secondary-ray-like rays through each the way wf_trace_kernel does (all child boxes tested
+// child until the node is full) and walks secondary-ray-like rays through each the way the trace kernel does (all child boxes tested
 // against [1e-4, tmax], hits ordered by entry distance, nearest first, no culling at the pop), counting node visits ("steps"), child-box
 // tests, leaf visits and triangle tests.  Exact fp32 boxes (the quantised frames of the device tree are a few % looser).
 //   usage: wide_bvh_probe scene.obj [rays=200000]            build: tools/wide_bvh_probe.sh
