@@ -9,10 +9,11 @@ says otherwise -- they are parity / roofline cases, the headline number is c2.
 
 One "step" = one complete render job of the scene already resident in HBM: clear the film, one mcpt_render call (a stream of
 [shade, trace] kernel launches over the HBM path pool), and -- with N > 1 ranks -- one RCCL all-reduce of the fp32
-films inside the timed region, the path's only exchange step.  Rank r of step s renders samples [(s*N + r)*spp, ...): work per
-GPU is fixed => "scaling": "weak".  `--shard tiles` is BASELINE.json's "pixel-tile shard" instead: rank r renders ALL samples of the
-8x8 pixel tiles t with t % N == r (mcpt_render_tiles), the films are disjoint and the same all-reduce assembles the image; the job
-is then fixed => "scaling": "strong".
+films inside the timed region, the path's only exchange step.  The JOB is fixed (the config's spp per step: cornell-box 1024 spp) and
+N ranks split it => "scaling": "strong" (round 4; the metric is quoted on a fixed job).  Default split = sample ranges: rank r renders
+its contiguous share of the step's sample indices for every pixel.  `--shard tiles` is BASELINE.json's "pixel-tile shard" instead: rank r
+renders ALL samples of the 8x8 pixel tiles t with t % N == r (mcpt_render_tiles); the films are disjoint and the same all-reduce assembles
+the image.  `--weak` keeps rounds 1-3's mode: every rank renders the config's spp per step (work per GPU fixed => "scaling": "weak").
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts N worker processes itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/
 MASTER_* set, 127.0.0.1 rendezvous) BEFORE anything touches the GPU or imports torch; under torch.distributed.run the
@@ -39,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0            # aggregate L2 bandwidth (same guide): the relevant ceiling while the scene is cache-resident
-CACHE_RESIDENT_BYTES = 16 << 20  # traversal data (8-wide nodes + triangle records) up to this size stays in L2 / Infinity Cache
+L2_BYTES, MALL_BYTES = 32 << 20, 256 << 20   # aggregate L2, Infinity Cache (same guide): where the traversal data (8-wide nodes + triangle records) can live
 # algorithmic bytes per unit of work with THIS build's layouts
 B_BOX, B_TRI = 10, 48            # an eighth of an 80-B eight-child node per child-box test; one 48-B {v0,e1,e2} record per triangle test
 B_RAY = 32 + 16                  # trace kernel: ray fetch (origin + direction records) + 16-B result write-back per ray
@@ -156,7 +157,7 @@ def cpu_baseline(pkg, cfg, scene, rays_per_path_ref, budget_s=20.0):
         _, c, t = o.render(spp, seed=2)
         rays = c["rays_primary"] + c["rays_continuation"] + c["rays_shadow"]
         omp_threads(1)
-        s1 = max(1, min(spp, int(6.0 / max(t1 * ncores / 8.0, 1e-3))))
+        s1 = max(1, min(spp, int(6.0 / max(t1 * ncores * 0.7, 1e-3))))        # ~6 s of single-thread work (the oracle's OpenMP loop scales ~0.7 x cores: r03's / 8 guess cost 92 s on c5)
         _, c1, tt1 = o.render(s1, seed=3)
         omp_threads(ncores)
         rays1 = c1["rays_primary"] + c1["rays_continuation"] + c1["rays_shadow"]
@@ -175,12 +176,15 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json configuration (default c2 = the headline)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per step")
     ap.add_argument("--shard", choices=["samples", "tiles"], default="samples",
-                    help="N > 1: each rank renders its own sample range of every pixel (default; weak scaling) or its interleaved share of the "
-                         "8x8 pixel tiles for all samples (BASELINE.json's 'pixel-tile shard'; strong scaling: the job is fixed)")
+                    help="N > 1: each rank renders its share of the step's sample range for every pixel (default) or its interleaved share of the "
+                         "8x8 pixel tiles for all samples (BASELINE.json's 'pixel-tile shard'); either way the job is fixed (strong scaling)")
+    ap.add_argument("--weak", action="store_true", help="N > 1, --shard samples: every rank renders the config's spp per step (rounds 1-3's mode; weak scaling)")
     ap.add_argument("--emulate-world", type=int, default=0, metavar="N",
-                    help="one GPU renders rank 0's share of an N-way STRONG-scaled split of the config's job (--shard samples: spp/N samples of every "
-                         "pixel; --shard tiles: all samples of every N-th 8x8 tile): per-rank time of an N-GPU run without the N GPUs "
-                         "(tools/scaling_emulation.py turns the sweep into profiles/r03_scaling_emulation.json)")
+                    help="one GPU renders one rank's share of an N-way strong-scaled split of the config's job (--shard samples: its share of the samples "
+                         "of every pixel; --shard tiles: all samples of every N-th 8x8 tile): per-rank time of an N-GPU run without the N GPUs "
+                         "(tools/scaling_emulation.py turns the sweep into profiles/r04_scaling_emulation.json)")
+    ap.add_argument("--emulate-rank", default="0", metavar="R|all", help="which rank of the emulated split to render; 'all' = every rank in turn, "
+                    "ms_per_step = the slowest (what an N-GPU step would take), per-rank times in emulated_ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--dry", action="store_true", help="launcher / collective rehearsal without a GPU: no rendering, films are synthetic")
@@ -219,15 +223,17 @@ def main():
         # max-over-ranks clock) on CPU tensors.  It renders nothing and reports no throughput.
         film = torch.zeros(H * W * 4, dtype=torch.float32)
         seen = []
+        weak = args.weak and args.shard == "samples"
         t0 = time.perf_counter()
         for s in range(args.warmup + args.steps):
             film.zero_()
-            first = mg.first_sample(s, rank, world, spp)
-            film.view(-1, 4)[:, 3] = float(spp)                      # what a render of spp samples leaves in the count plane
+            if weak: first, n = mg.first_sample(s, rank, world, spp), spp
+            else: first, n = mg.sample_share(s, rank, world, spp)
+            film.view(-1, 4)[:, 3] = float(n)                        # what a render of n samples leaves in the count plane
             mg.all_reduce_film(film)
             seen.append(first)
         dt = time.perf_counter() - t0
-        ok = bool((film.view(-1, 4)[:, 3] == float(spp * n_ranks)).all())
+        ok = bool((film.view(-1, 4)[:, 3] == float(spp * n_ranks if weak else spp)).all())
         t_all = torch.tensor([dt], dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
@@ -235,7 +241,8 @@ def main():
             print(json.dumps({"metric": "Mray/s (primary+secondary), %s %dspp" % (cfg["scene"], cfg["spp"]), "value": 0.0, "unit": "Mray/s", "dry": True,
                               "n_gpus": n_ranks, "rccl_ranks": n_ranks, "backend": args.backend, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(float(t_all.item()) / max(1, args.steps) * 1e3, 3), "count_plane_ok": ok,
-                              "first_samples_rank0": seen, "config": {"workload": cfg["label"], "spp_per_step_per_gpu": spp}}), flush=True)
+                              "first_samples_rank0": seen, "scaling": "weak" if weak else "strong",
+                              "config": {"workload": cfg["label"], "spp_per_step": spp, "spp_per_rank": spp if weak else mg.sample_share(0, rank, world, spp)[1]}}), flush=True)
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         sys.exit(0 if ok else 1)
@@ -257,18 +264,23 @@ def main():
     r.set_torch_stream(side)
 
     emu = args.emulate_world if world == 1 else 0
-    if emu > 1 and args.shard == "samples":
-        spp = max(1, spp // emu)            # rank 0's share of the job's samples
+    job_spp = spp                           # samples per pixel of ONE step's job (the config's spp per step)
+    split = emu if emu > 1 else n_ranks     # ranks the job is divided over
+    strong = not (args.weak and args.shard == "samples")
 
-    def step(s):                            # one step = one complete render job: clear the film, render this rank's sample range, sum the films
+    def share(rk):                          # (first sample offset inside a step, samples) of rank rk under the sample-range split
+        if not strong: return rk * job_spp, job_spp
+        return mg.sample_share(0, rk, split, job_spp)
+
+    def step(s, rk):                        # one step = one complete render job: clear the film, render rank rk's share, sum the films
+        step_base = s * job_spp * (1 if strong else split)
         with torch.cuda.stream(side):
             accum.zero_()
-            if emu > 1 and args.shard == "tiles":
-                r.render_tiles(spp, 20251004, s * spp, emu, 0)
-            elif args.shard == "tiles":
-                r.render_tiles(spp, 20251004, s * spp, *mg.tile_shard(rank, world))
+            if args.shard == "tiles":
+                r.render_tiles(job_spp, 20251004, step_base, *mg.tile_shard(rk, split))
             else:
-                r.render(spp, seed=20251004, first_sample=mg.first_sample(s, rank, world, spp))
+                lo, n = share(rk)
+                if n: r.render(n, seed=20251004, first_sample=step_base + lo)
             mg.all_reduce_film(accum)       # RCCL sum over xGMI, ordered after the render on `side` (no-op for one rank)
 
     def fence():
@@ -276,21 +288,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for s in range(args.warmup):
-        step(s)
-    fence()
-    r.reset_counters()
-    fence()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(args.warmup + s)
-    fence()
-    dt = time.perf_counter() - t0
-    c = r.counters()
-    want_count = float(spp if args.shard == "tiles" else spp * n_ranks)
-    if emu > 1 and args.shard == "tiles":   # rank 0 of an emulated split owns every emu-th tile only
+    def timed(rk):
+        for s in range(args.warmup):
+            step(s, rk)
+        fence()
+        r.reset_counters()
+        fence()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            step(args.warmup + s, rk)
+        fence()
+        return time.perf_counter() - t0, r.counters()
+
+    emu_ranks = None
+    if emu > 1 and args.emulate_rank == "all":        # every rank of the split in turn, on this one GPU; the slowest is what a step would take
+        emu_ranks = []
+        dt, c = 0.0, None
+        for rk in range(emu):
+            dt_k, c_k = timed(rk)
+            emu_ranks.append({"rank": rk, "ms_per_step": round(dt_k / args.steps * 1e3, 3), "rays": int(c_k.rays)})
+            if dt_k > dt: dt, c = dt_k, c_k
+        my_rank = max(range(emu), key=lambda k: emu_ranks[k]["ms_per_step"])
+    else:
+        my_rank = int(args.emulate_rank) if emu > 1 else rank
+        dt, c = timed(my_rank)
+    spp = job_spp if args.shard == "tiles" else share(my_rank)[1]          # samples per pixel this rank renders per step
+    want_count = float(job_spp if strong else job_spp * n_ranks)
+    if emu > 1 and args.shard == "tiles":   # one rank of an emulated split owns every emu-th tile only
         cnt = accum.view(H, W, 4)[:, :, 3]
-        film_ok = bool(((cnt == 0) | (cnt == float(spp))).all().item()) and abs(float((cnt > 0).float().mean().item()) - 1.0 / emu) < 0.02
+        film_ok = bool(((cnt == 0) | (cnt == float(job_spp))).all().item()) and abs(float((cnt > 0).float().mean().item()) - 1.0 / emu) < 0.02
+    elif emu > 1:
+        film_ok = bool((accum.view(-1, 4)[:, 3] == float(share(emu - 1 if emu_ranks else my_rank)[1])).all().item())
     else:
         film_ok = bool((accum.view(-1, 4)[:, 3] == want_count).all().item())   # every pixel got all the samples of the last step, from every rank
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -317,17 +345,19 @@ def main():
         algo_bytes = trace_bytes_per_ray * rays_per_launch
         achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
         scene_bytes = int(info.traversal_bytes)                       # wide nodes + triangle test records, from the library
-        resident = scene_bytes <= CACHE_RESIDENT_BYTES
+        resident = scene_bytes <= L2_BYTES
+        residency = "L2" if scene_bytes <= L2_BYTES else "Infinity Cache (MALL)" if scene_bytes <= MALL_BYTES else "HBM"
         # ---- measured HBM traffic / VALU issue / lane utilisation: PMC counters cannot be read inside this process; they come from the
         # committed rocprofv3 --pmc passes of the same workload and build (tools/r03_profile.sh -> profiles/r03_traffic.json), per traced ray,
         # x this run's rays per launch / rays per second
         traffic = None; traffic_source = None; pmc = {}
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if os.path.exists(tpath):
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r04_traffic.json"), os.path.join(ROOT, "profiles", "r03_traffic.json")) if os.path.exists(q)), None)
+        tname = "profiles/" + os.path.basename(tpath) if tpath else None
+        if tpath:
             pmc = json.load(open(tpath)).get(args.config, {})
             if pmc.get("wf_trace_kernel_hbm_bytes_per_ray"):
                 traffic = int(pmc["wf_trace_kernel_hbm_bytes_per_ray"] * rays_per_launch)
-                traffic_source = "profiles/r03_traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (not this run), bytes per ray x this run's rays per launch" % args.config
+                traffic_source = "%s[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (not this run), bytes per ray x this run's rays per launch" % (tname, args.config)
         rays_per_s = total_rays / dt / max(1, n_ranks)                     # this GPU's share of the job's ray rate
         hbm_measured = None
         if pmc.get("wf_trace_kernel_hbm_bytes_per_ray") and pmc.get("wf_shade_kernel_hbm_bytes_per_ray"):
@@ -336,11 +366,18 @@ def main():
                             "trace_bytes_per_ray": tb, "shade_bytes_per_ray": sb,
                             "trace_GBps": round(tb * rays_per_s / 1e9, 1), "shade_GBps": round(sb * rays_per_s / 1e9, 1),
                             "total_GBps": round((tb + sb) * rays_per_s / 1e9, 1), "frac_of_hbm_peak": round((tb + sb) * rays_per_s / 1e9 / HBM_PEAK_GBS, 4),
-                            "source": "profiles/r03_traffic.json[%s]" % args.config}
+                            "fetch_correction": pmc.get("fetch_correction_note"),
+                            "source": "%s[%s]" % (tname, args.config)}
         n_streams = 2 if (c.shade_ms_total > 0 and launches >= 2) else 1
         per_stream_ms = launches / max(1, args.steps) / n_streams * (trace_ms + shade_ms)
         frac_alg = round(achieved / HBM_PEAK_GBS, 4)
-        roofline = {"bound": "valu-issue/latency" if resident else "hbm",
+        # what binds, decided from the counters the line carries (not from the scene's size): the memory system when the measured HBM-side traffic is
+        # at least half of the peak; else VALU issue when the two kernels keep the SIMDs' vector ALUs busy most of the time (SQ_ACTIVE_INST_VALU over
+        # the SIMD-cycles of the render: `valu_busy_frac`); else latency / occupancy
+        hbm_frac = hbm_measured["frac_of_hbm_peak"] if hbm_measured else None
+        valu_busy = pmc.get("valu_busy_frac", pmc.get("valu_issue_frac"))
+        bound = "hbm" if (hbm_frac is not None and hbm_frac >= 0.5) else "valu-issue" if (valu_busy is not None and valu_busy >= 0.6) else "latency" if (hbm_frac is not None or valu_busy is not None) else ("valu-issue" if resident else "hbm")
+        roofline = {"bound": bound, "bound_rule": "hbm if measured HBM-side traffic >= 0.5 of peak, else valu-issue if valu_busy_frac >= 0.6, else latency (counters: %s)" % tname,
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": frac_alg, "frac_algorithmic": frac_alg,
                     "frac_note": "ALGORITHMIC bytes of the dominant kernel / its launch time / HBM peak (the contract's definition); the bytes the "
@@ -350,10 +387,10 @@ def main():
                     "rays_per_launch": int(rays_per_launch),
                     "algorithmic_bytes_per_ray": round(trace_bytes_per_ray, 1),
                     "box_tests_per_ray": round(ci.box_tests / max(1, ci.rays), 2), "tri_tests_per_ray": round(ci.tri_tests / max(1, ci.rays), 2),
-                    "traversal_data_bytes": int(scene_bytes), "cache_resident": resident,
+                    "traversal_data_bytes": int(scene_bytes), "cache_resident": resident, "traversal_data_lives_in": residency,
                     "l2_relative": {"traversal_GBps": round(trav_bytes_per_ray * rays_per_launch / (trace_ms * 1e-3) / 1e9, 1), "l2_peak_GBps": L2_PEAK_GBS,
                                     "frac": round(trav_bytes_per_ray * rays_per_launch / (trace_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4)},
-                    "valu_issue_frac": pmc.get("valu_issue_frac"), "valu_issue_note": pmc.get("valu_issue_note"),
+                    "valu_busy_frac": valu_busy, "valu_issue_note": pmc.get("valu_issue_note"),
                     "valu_lane_utilisation": pmc.get("wf_trace_kernel_valu_lane_utilisation"),
                     "salu_to_valu_instructions": pmc.get("wf_trace_kernel_salu_to_valu"),
                     "inner_steps_per_ray": pmc.get("wf_trace_kernel_inner_steps_per_ray"),
@@ -364,19 +401,20 @@ def main():
                     "reconciliation": "each of the %d sub-pipeline streams runs launches_per_step / %d x (trace %.4f + shade %.4f ms) = %.1f ms of "
                                       "back-to-back kernels per step; ms_per_step = %.1f (the two streams overlap: a kernel's duration is that of a kernel "
                                       "sharing the GPU with the other stream's)" % (n_streams, n_streams, trace_ms, shade_ms, per_stream_ms, dt / args.steps * 1e3),
-                    "note": ("scene is cache-resident (%.1f MB of nodes+triangles): the algorithmic traversal bytes are served by LDS/L1/L2, HBM only "
-                             "carries the path-pool stream, and what binds is VALU issue under divergence + memory latency (valu_issue_frac, "
-                             "valu_lane_utilisation) -- `frac` (vs HBM peak) is the contract's algorithmic figure, `hbm_measured` the real traffic" if resident else
-                             "scene (%.1f MB of nodes+triangles) exceeds L2 / Infinity Cache: traversal fetches reach HBM")
-                            % (scene_bytes / 1e6)}
+                    "note": ("%.1f MB of nodes + triangle records live in %s%s; `frac` (vs HBM peak) is the contract's algorithmic figure -- for cache-resident data a cache "
+                             "bandwidth --, `hbm_measured` what the L2's memory side moved (FETCH_SIZE counts Infinity-Cache hits too: for data that fits the "
+                             "256-MB MALL that is not all HBM)") % (scene_bytes / 1e6, residency, ": HBM carries only the path-pool stream" if resident else "")}
         rpp_ref = (c.rays_primary + c.rays_continuation + c.self_shadow_tests) / max(1, c.paths)
         out = {
             "metric": "Mray/s (primary+secondary), %s %dspp" % (cfg["scene"], cfg["spp"]), "value": round(total_rays / dt / 1e6, 2), "unit": "Mray/s",
             "n_gpus": n_ranks, "rccl_ranks": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if (args.shard == "tiles" and n_ranks > 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"name": args.config,
-                       "workload": "%s, %d spp/step/GPU%s, MIS integrator, reference-faithful shadow rays" % (
-                           cfg["label"], spp, "" if spp == cfg["spp"] else " (of the config's %d)" % cfg["spp"]),
+                       "workload": "%s, %d spp per step%s%s, MIS integrator, reference-faithful shadow rays" % (
+                           cfg["label"], job_spp, "" if job_spp == cfg["spp"] else " (of the config's %d)" % cfg["spp"],
+                           "" if split == 1 else (", EVERY one of %d ranks renders that (weak)" % split if not strong else
+                                                  ", split over %d ranks by %s (%d spp per rank)" % (split, "8x8 tiles" if args.shard == "tiles" else "sample range", spp))),
+                       "spp_per_step": job_spp, "spp_per_rank": spp,
                        "n_tris": int(info.n_tris), "wide_bvh": "%d-wide, %d nodes, depth %d" % (info.wide_width, info.wide_nodes, info.wide_depth), "scene_device_bytes": int(info.device_bytes),
                        "parallelism": "%s shard x%d + RCCL all-reduce of the %dx%dx4 fp32 film" % (
                            "interleaved 8x8 pixel-tile" if args.shard == "tiles" else "sample-range", n_ranks, W, H)},
@@ -386,7 +424,7 @@ def main():
                               "so mpath_per_s is the like-for-like pair" % (total_rays / max(1.0, total_paths), rpp_ref),
             "self_shadow_rate": round(c.self_shadow_hits / max(1, c.self_shadow_tests), 4),
             "film_count_plane_ok": film_ok,
-            "emulated_world": emu if emu > 1 else None,
+            "emulated_world": emu if emu > 1 else None, "emulated_rank": (my_rank if emu > 1 else None), "emulated_ranks": emu_ranks,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MCPT_ABI_VERSION 3
+#define MCPT_ABI_VERSION 4
 
 typedef enum mcpt_status {
     MCPT_OK = 0,
@@ -175,6 +175,10 @@ mcpt_status mcpt_clear_accum(mcpt_ctx* ctx);
 /* Scene::getPixelsColor (Scene.cpp:23-33) on the device: mean -> clamp[0,1] -> pow(.,0.5) -> *255.99 -> u8.
  * flip_y != 0 additionally applies Scene::save_image's vertical flip (Scene.cpp:40-46). */
 mcpt_status mcpt_tonemap(mcpt_ctx* ctx, uint8_t* rgb_host, int flip_y);
+/* ABI 4: the same without the last host copy -- *out_rgb points at the context's own pinned host image (width * height * 3 bytes), valid until
+ * the next tonemap call on this context or mcpt_destroy.  This is Scene::getPixelsColor's own contract (Scene.cpp:23-33 returns a pointer
+ * into a vector the next call overwrites), and what the reference's loop calls after EVERY render(scene) (main.cpp:26-33). */
+mcpt_status mcpt_tonemap_map(mcpt_ctx* ctx, int flip_y, const uint8_t** out_rgb);
 
 /* mcpt_tonemap of any film of this context's size resident on its device (e.g. several devices' films summed into a scratch buffer). */
 mcpt_status mcpt_tonemap_buffer(mcpt_ctx* ctx, const void* device_rgba, uint8_t* rgb_host, int flip_y);

@@ -171,6 +171,7 @@ def load_library() -> C.CDLL:
         "mcpt_bind_accum": [vp, vp],
         "mcpt_clone_to_device": [vp, C.c_int32, P(vp)],
         "mcpt_tonemap_buffer": [vp, vp, vp, C.c_int],
+        "mcpt_tonemap_map": [vp, C.c_int, C.POINTER(C.c_void_p)],
         "mcpt_accum_device_ptr": [vp, P(vp)],
         "mcpt_set_stream": [vp, vp],
         "mcpt_set_null_stream": [vp],
@@ -198,7 +199,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "mcpt_create", "mcpt_destroy", "mcpt_clone_to_device", "mcpt_tonemap_buffer", "mcpt_check_scene", "mcpt_get_scene_info", "mcpt_last_error", "mcpt_abi_version",
-    "mcpt_render", "mcpt_render_tiles", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap",
+    "mcpt_render", "mcpt_render_tiles", "mcpt_sync", "mcpt_read_accum", "mcpt_write_accum", "mcpt_clear_accum", "mcpt_tonemap", "mcpt_tonemap_map",
     "mcpt_get_counters", "mcpt_reset_counters", "mcpt_bind_accum", "mcpt_accum_device_ptr", "mcpt_set_stream",
     "mcpt_set_null_stream", "mcpt_probe_trace", "mcpt_probe_trace4", "mcpt_probe_cast_ray", "mcpt_probe_hit_shade", "mcpt_probe_bsdf", "mcpt_probe_sample_light",
     "mcpt_probe_paths", "mcpt_probe_rng", "mcpt_probe_texture",
@@ -287,6 +288,12 @@ class Renderer:
         out = np.zeros((self.height, self.width, 3), np.uint8)
         self._check(self.lib.mcpt_tonemap(self.ctx, _ptr(out), 1 if flip_y else 0))
         return out
+
+    def tonemap_map(self, flip_y=False) -> np.ndarray:
+        """mcpt_tonemap_map: a copy of the context's own pinned image (the C pointer stays valid until the next tonemap call)."""
+        p = C.c_void_p()
+        self._check(self.lib.mcpt_tonemap_map(self.ctx, 1 if flip_y else 0, C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.height, self.width, 3)).copy()
 
     def accum_device_ptr(self) -> int:
         p = C.c_void_p()

@@ -32,8 +32,11 @@ struct mcpt_ctx {
     DevBuf nodes, nodes8, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, light_pos64, texels, accum_own, counters;
     float4* accum = nullptr;           // bound accumulator (own or external)
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timing_pending = false;
+    // HIP-event brackets of the render calls whose duration has not been read yet: a ring, so that a call does not have to wait for the one
+    // before it (the reference's loop issues a call per sample); resolve_timing() reads the finished ones, oldest first
+    static constexpr uint32_t TIMED = 16;
+    hipEvent_t ev0[TIMED] = {}, ev1[TIMED] = {};
+    uint32_t timed_head = 0, timed_tail = 0;      // calls [timed_tail, timed_head) are outstanding
     double last_kernel_ms = 0.0, total_kernel_ms = 0.0;
     uint64_t launches = 0;
     mcpt_scene_info info{};
@@ -53,6 +56,12 @@ struct mcpt_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t done_ev = nullptr;
         uint64_t last_iterations = 0, last_timed = 0;
+        // Known-length jobs (every item has its own slot and one sample, depth-limited: render_wavefront) are enqueued whole and NOT waited for:
+        // the control-block snapshot taken after their last iteration is looked at later -- by the next call that drains the stream, or when the
+        // ring of snapshots is full -- so consecutive one-sample calls (the reference's loop, main.cpp:26-33) cost the host only their launches.
+        struct Verdict { uint32_t ring_slot, it, n_shared; };
+        std::vector<Verdict> verdicts;     // oldest first; at most RING - 2 outstanding
+        uint32_t ring_next = 0;            // next h_ctl / chk_ev slot this lane uses (jobs of either kind take them in turn)
     };
     std::vector<WfLane> lanes;
     hipEvent_t fork_ev = nullptr;
@@ -67,6 +76,9 @@ struct mcpt_ctx {
     bool binary_ok = true;                // the binary cross-check tree fits its kernels' stack (false: a deep device-built tree)
     uint32_t wide_depth = 0;              // depth of the 8-wide tree the wavefront trace kernel walks
     std::vector<int32_t> h_tri_face;      // leaf order -> face index, fetched on first use by mcpt_probe_trace4
+    // Scene::getPixelsColor every frame (main.cpp:26-33): the tonemapped film's device buffer and its pinned host image live as long as the
+    // context (allocated by the first tonemap call) -- no hipMalloc / hipMemset / hipFree per frame
+    DevBuf tone_dev; uint8_t* tone_host = nullptr;
 };
 
 namespace {
@@ -97,9 +109,9 @@ void destroy_ctx(mcpt_ctx* c) {
         if (L.done_ev) (void)hipEventDestroy(L.done_ev);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
+    c->tone_dev.free_(); if (c->tone_host) (void)hipHostFree(c->tone_host);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (uint32_t i = 0; i < mcpt_ctx::TIMED; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -154,7 +166,7 @@ static mcpt_status finish_ctx(mcpt_ctx* c) {
     auto bail = [&](hipError_t he, const char* what) { return hip_fail(he, what); };
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     c->stream = c->own_stream;
-    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (uint32_t i = 0; i < mcpt_ctx::TIMED; i++) if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess || (e = hipEventCreate(&c->ev1[i])) != hipSuccess) return bail(e, "hipEventCreate");
     const size_t accum_bytes = size_t(c->width) * c->height * sizeof(float4);
     if ((e = c->accum_own.alloc(accum_bytes)) != hipSuccess) return bail(e, "alloc accumulator");
     if ((e = hipMemset(c->accum_own.p, 0, accum_bytes)) != hipSuccess) return bail(e, "clear accumulator");
@@ -377,17 +389,25 @@ mcpt_status mcpt_get_scene_info(const mcpt_ctx* ctx, mcpt_scene_info* out) {
     return MCPT_OK;
 }
 
-static mcpt_status resolve_timing(mcpt_ctx* c) {
-    if (c->timing_pending) {
-        HIP_TRY(hipEventSynchronize(c->ev1));
+static mcpt_status check_pending_jobs(mcpt_ctx* ctx);
+// Reads the durations of finished render calls (oldest first).  `block`: wait for all of them -- every entry point that drains the stream
+// anyway, and a render call when per-kernel timing is on (its sampled kernel events are per call).  Otherwise only what has finished.
+static mcpt_status resolve_timing(mcpt_ctx* c, bool block = true) {
+    while (c->timed_tail != c->timed_head) {
+        const uint32_t k = c->timed_tail % mcpt_ctx::TIMED;
+        if (block) HIP_TRY(hipEventSynchronize(c->ev1[k]));
+        else {
+            const hipError_t q = hipEventQuery(c->ev1[k]);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return hip_fail(q, "hipEventQuery");
+        }
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->last_kernel_ms = ms; c->total_kernel_ms += ms; c->timing_pending = false;
-        if (c->use_wavefront) {
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0[k], c->ev1[k]));
+        c->last_kernel_ms = ms; c->total_kernel_ms += ms; c->timed_tail++;
+        if (c->use_wavefront && c->time_kernels && c->timed_tail == c->timed_head) {   // (per-kernel timing: calls are resolved one at a time, see mcpt_render_tiles)
             double sh = 0.0, tr = 0.0;
             for (auto& L : c->lanes) {
-                c->total_iterations += L.last_iterations;
-                if (c->time_kernels && L.last_timed) {                       // sampled iterations stand for all of them
+                if (L.last_timed) {                                          // sampled iterations stand for all of them
                     double s_ = 0.0, t_ = 0.0;
                     for (uint64_t i = 0; i < L.last_timed; i++) {
                         float a_ = 0.f, b_ = 0.f;
@@ -403,7 +423,7 @@ static mcpt_status resolve_timing(mcpt_ctx* c) {
             c->last_shade_ms = sh; c->last_trace_ms = tr; c->total_shade_ms += sh; c->total_trace_ms += tr;
         }
     }
-    return MCPT_OK;
+    return block ? check_pending_jobs(c) : MCPT_OK;                        // (everything has finished: the known-length jobs' snapshots are in)
 }
 
 // A sub-pipeline's path pool, allocated on first use and grown (never shrunk) to the largest job seen: a 48 x 48 film gets a few hundred KB,
@@ -426,6 +446,32 @@ static mcpt_status ensure_pool(mcpt_ctx* ctx, mcpt_ctx::WfLane& L, uint32_t P) {
     }
     HIP_TRY(hipStreamSynchronize(nullptr));                              // (the fills ran on the default stream)
     L.pool.P = P;
+    return MCPT_OK;
+}
+
+// Look at the snapshots known-length jobs left behind.  `block`: wait for every one of them (the caller has synchronised, or is about to
+// synchronise, the stream anyway); otherwise only those that have arrived.  A job that did not finish inside its bound, or whose trace kernel
+// raised the watchdog flag, is an internal error and is reported by whichever call gets here first.
+static mcpt_status check_lane_verdicts(mcpt_ctx::WfLane& L, bool block) {
+    while (!L.verdicts.empty()) {
+        const mcpt_ctx::WfLane::Verdict v = L.verdicts.front();
+        if (block) HIP_TRY(hipEventSynchronize(L.chk_ev[v.ring_slot]));
+        else {
+            const hipError_t q = hipEventQuery(L.chk_ev[v.ring_slot]);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return hip_fail(q, "hipEventQuery");
+        }
+        L.verdicts.erase(L.verdicts.begin());
+        const IterCtl& s = L.h_ctl[v.ring_slot];
+        if (s.pad[0]) return fail(MCPT_ERR_HIP, "trace kernel watchdog: a wave did not finish its ray list (internal error)");
+        bool items_left = false;
+        for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) items_left |= s.item_cursor[q].v < wf_shard_capacity(v.n_shared, q);
+        if (s.any_active[v.it & 3] != 0 || items_left) return fail(MCPT_ERR_HIP, "a known-length job did not finish within its iteration bound (internal error)");
+    }
+    return MCPT_OK;
+}
+static mcpt_status check_pending_jobs(mcpt_ctx* ctx) {
+    for (auto& L : ctx->lanes) { mcpt_status st = check_lane_verdicts(L, true); if (st != MCPT_OK) return st; }
     return MCPT_OK;
 }
 
@@ -455,7 +501,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             my_tiles = (tiles - k + n_lanes - 1) / n_lanes; r.p.n_owned = uint32_t(my_tiles);
         } else {
             const uint32_t lo = uint32_t(uint64_t(p0.spp) * k / n_lanes), hi = uint32_t(uint64_t(p0.spp) * (k + 1) / n_lanes);   // (equal shares: 40 / 60 and 35 / 65 splits, so that the two pools do not drain together, were 6 - 10 % slower)
-            if (hi == lo) { r.done = true; ctx->lanes[k].last_iterations = 0; continue; }
+            if (hi == lo) { r.done = true; ctx->lanes[k].last_iterations = 0; ctx->lanes[k].last_timed = 0; continue; }
             r.p.spp = hi - lo; r.p.first_sample = p0.first_sample + lo;
         }
         if (r.p.samples_per_item > r.p.spp) r.p.samples_per_item = r.p.spp;
@@ -489,6 +535,12 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             r.p.priv_items = uint32_t(0.9 * double(r.n_items) / double(n_blocks)) & ~63u;   // whole 64-item units (block b owns unit k * n_blocks + b)
             r.p.shared_base = n_blocks * r.p.priv_items;
             r.n_shared = r.n_items - r.p.shared_base;
+        }
+        {   // snapshots of earlier known-length jobs on this sub-pipeline: a polled job starts with none outstanding (it takes the ring's slots
+            // in turn from 0), a known-length one needs a free slot for its own
+            mcpt_ctx::WfLane& L = ctx->lanes[k];
+            mcpt_status vs = check_lane_verdicts(L, r.bound == 0); if (vs != MCPT_OK) return vs;
+            if (L.verdicts.size() > RING - 2) { vs = check_lane_verdicts(L, true); if (vs != MCPT_OK) return vs; }
         }
         r.active = true; n_active++;
     }
@@ -539,14 +591,6 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             if (!r.active || r.done) continue;
             mcpt_ctx::WfLane& L = ctx->lanes[k];
             IterCtl* ctl = static_cast<IterCtl*>(L.ctl_buf.p);
-            auto awaits_verdict = [](const Run& x) { return x.bound && x.it == x.bound && x.seen < x.issued; };
-            if (awaits_verdict(r)) {                                        // known-length job, all iterations issued: wait for its snapshot --
-                bool others = false;                                        // blocking only when no other sub-pipeline has launches left to issue
-                for (uint32_t j = 0; j < n_lanes; j++) others |= j != k && runs[j].active && !runs[j].done && !awaits_verdict(runs[j]);
-                mcpt_status ps = poll(L, r, !others); if (ps != MCPT_OK) return ps;
-                if (r.done) continue;
-                if (r.seen < r.issued) { all_done = false; continue; }
-            }
             const bool timed = ctx->time_kernels && r.it % ctx->time_kernels == 0;
             HIP_TRY(k_event(L, r, timed));
             HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_shared, accum, cnt, L.stream));
@@ -554,7 +598,15 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(L.ovf_buf.p), L.stream));
             HIP_TRY(k_event(L, r, timed));
             r.it++;
-            if (r.bound ? (r.it >= r.bound && (r.it - r.bound) % CHECK == 0) : r.it % CHECK == 0) {
+            if (r.bound && r.it == r.bound) {                               // known-length job: all of it is enqueued; its verdict is read later
+                const uint32_t q = L.ring_next++ % RING;
+                HIP_TRY(hipMemcpyAsync(&L.h_ctl[q], ctl, sizeof(IterCtl), hipMemcpyDeviceToHost, L.stream));
+                HIP_TRY(hipEventRecord(L.chk_ev[q], L.stream));
+                L.verdicts.push_back({q, r.it - 1, r.n_shared});
+                r.done = true;
+                continue;
+            }
+            if (!r.bound && r.it % CHECK == 0) {
                 mcpt_status ps = poll(L, r, r.issued - r.seen >= 2); if (ps != MCPT_OK) return ps;   // at most 2 checks (8 iterations) ahead
                 if (!r.done) {
                     const uint32_t q = r.issued % RING;
@@ -573,6 +625,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
         if (!runs[k].active) continue;
         mcpt_ctx::WfLane& L = ctx->lanes[k];
         L.last_iterations = runs[k].it; L.last_timed = runs[k].kev / 3;
+        ctx->total_iterations += runs[k].it;
         HIP_TRY(hipEventRecord(L.done_ev, L.stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, L.done_ev, 0));            // join: the caller's stream continues after every sub-pipeline
     }
@@ -586,7 +639,9 @@ mcpt_status mcpt_render_tiles(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32
     if (tile_mod == 0 || tile_rem >= tile_mod) return fail(MCPT_ERR_INVALID_ARG, "mcpt_render_tiles: need tile_rem < tile_mod");
     if (spp == 0) return MCPT_OK;
     if (!ctx->use_wavefront && !ctx->binary_ok) return fail(MCPT_ERR_BVH_DEPTH, "the binary tree of this (device-built) scene is deeper than the megakernel's traversal stack");
-    st = resolve_timing(ctx); if (st != MCPT_OK) return st;
+    // durations of earlier calls: read what has finished; wait only when the ring of event pairs is full -- or when per-kernel timing is on,
+    // whose sampled kernel events belong to one call at a time
+    st = resolve_timing(ctx, ctx->time_kernels != 0 || ctx->timed_head - ctx->timed_tail >= mcpt_ctx::TIMED - 1); if (st != MCPT_OK) return st;
     RenderParams p; std::memset(&p, 0, sizeof p);
     p.spp = spp; p.first_sample = first_sample;
     p.tiles_x = uint32_t((ctx->width + 7) / 8); p.tiles_y = uint32_t((ctx->height + 7) / 8);
@@ -621,14 +676,15 @@ mcpt_status mcpt_render_tiles(mcpt_ctx* ctx, uint32_t spp, uint64_t seed, uint32
     p.max_depth = ctx->opts.max_depth; p.flags = ctx->opts.flags; p.integrator = ctx->opts.integrator;
     p.seed_lo = uint32_t(seed); p.seed_hi = uint32_t(seed >> 32);
     if (tiles * p.chunks > 0x3ffffffull) return fail(MCPT_ERR_UNSUPPORTED, "launch too large: lower spp per call or raise samples_per_item");
-    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    const uint32_t tk = ctx->timed_head % mcpt_ctx::TIMED;
+    HIP_TRY(hipEventRecord(ctx->ev0[tk], ctx->stream));
     if (ctx->use_wavefront) {
         st = render_wavefront(ctx, p, ctx->accum); if (st != MCPT_OK) return st;
     } else {
         HIP_TRY(launch_render(ctx->dev, p, ctx->accum, static_cast<DevCounters*>(ctx->counters.p), ctx->stream));
     }
-    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->timing_pending = true; ctx->launches++;
+    HIP_TRY(hipEventRecord(ctx->ev1[tk], ctx->stream));
+    ctx->timed_head++; ctx->launches++;
     return MCPT_OK;
 }
 
@@ -659,15 +715,37 @@ mcpt_status mcpt_clear_accum(mcpt_ctx* ctx) {
     return MCPT_OK;
 }
 
+// tonemap_kernel over `film` into the context's persistent u8 buffer, copied to its pinned host image on the context's stream; returns after
+// the stream has drained (the image is complete).  The kernel writes every byte: nothing to clear.
+static mcpt_status tonemap_to_pinned(mcpt_ctx* ctx, const float4* film, int flip_y) {
+    const size_t n = size_t(ctx->width) * ctx->height;
+    if (!ctx->tone_dev.p) {
+        HIP_TRY(ctx->tone_dev.alloc(3 * n));
+        HIP_TRY(hipHostMalloc((void**)&ctx->tone_host, 3 * n ? 3 * n : 16, hipHostMallocDefault));
+    }
+    HIP_TRY(launch_tonemap(film, static_cast<uint8_t*>(ctx->tone_dev.p), ctx->width, ctx->height, flip_y, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->tone_host, ctx->tone_dev.p, 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return resolve_timing(ctx);
+}
+
 mcpt_status mcpt_tonemap(mcpt_ctx* ctx, uint8_t* rgb_host, int flip_y) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
     if (!rgb_host) return fail(MCPT_ERR_INVALID_ARG, "null output");
-    const size_t n = size_t(ctx->width) * ctx->height;
-    Scratch s; uint8_t* d_rgb = nullptr;
-    HIP_TRY(s.out(3 * n, &d_rgb));
-    HIP_TRY(launch_tonemap(ctx->accum, d_rgb, ctx->width, ctx->height, flip_y, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(rgb_host, d_rgb, 3 * n, hipMemcpyDeviceToHost));
+    st = tonemap_to_pinned(ctx, ctx->accum, flip_y); if (st != MCPT_OK) return st;
+    std::memcpy(rgb_host, ctx->tone_host, 3 * size_t(ctx->width) * ctx->height);
+    return MCPT_OK;
+}
+
+/* The same without the last copy: *out_rgb points at the context's own pinned host image (width * height * 3 bytes), valid until the next
+ * tonemap call on this context or its destruction -- what Scene::getPixelsColor hands out (Scene.cpp:23-33 returns a pointer into the
+ * Scene's own vector, overwritten by the next call). */
+mcpt_status mcpt_tonemap_map(mcpt_ctx* ctx, int flip_y, const uint8_t** out_rgb) {
+    mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
+    if (!out_rgb) return fail(MCPT_ERR_INVALID_ARG, "null output");
+    *out_rgb = nullptr;
+    st = tonemap_to_pinned(ctx, ctx->accum, flip_y); if (st != MCPT_OK) return st;
+    *out_rgb = ctx->tone_host;
     return MCPT_OK;
 }
 
@@ -676,12 +754,8 @@ mcpt_status mcpt_tonemap(mcpt_ctx* ctx, uint8_t* rgb_host, int flip_y) {
 mcpt_status mcpt_tonemap_buffer(mcpt_ctx* ctx, const void* device_rgba, uint8_t* rgb_host, int flip_y) {
     mcpt_status st = use(ctx); if (st != MCPT_OK) return st;
     if (!rgb_host || !device_rgba) return fail(MCPT_ERR_INVALID_ARG, "null argument");
-    const size_t n = size_t(ctx->width) * ctx->height;
-    Scratch s; uint8_t* d_rgb = nullptr;
-    HIP_TRY(s.out(3 * n, &d_rgb));
-    HIP_TRY(launch_tonemap(static_cast<const float4*>(device_rgba), d_rgb, ctx->width, ctx->height, flip_y, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(rgb_host, d_rgb, 3 * n, hipMemcpyDeviceToHost));
+    st = tonemap_to_pinned(ctx, static_cast<const float4*>(device_rgba), flip_y); if (st != MCPT_OK) return st;
+    std::memcpy(rgb_host, ctx->tone_host, 3 * size_t(ctx->width) * ctx->height);
     return MCPT_OK;
 }
 

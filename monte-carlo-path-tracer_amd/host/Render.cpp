@@ -66,6 +66,13 @@ void Render::flush_into(Scene& scene) {
     if (mcpt_read_accum(ctx, film.data()) != MCPT_OK || mcpt_clear_accum(ctx) != MCPT_OK) { std::cerr << "Error: film read-back: " << mcpt_last_error() << std::endl; return; }
     scene.add_film(film.data());
 }
+const Color3b* Render::tonemapped(Scene& scene) {
+    static_assert(sizeof(Color3b) == 3, "mcpt_tonemap_map's image is read as Color3b[]");
+    if (!ctx || !dirty || &scene != target) return nullptr;          // (nothing held: the host path shows what an empty film shows)
+    const uint8_t* px = nullptr;
+    if (mcpt_tonemap_map(ctx, 0, &px) != MCPT_OK) { std::cerr << "Error: mcpt_tonemap_map: " << mcpt_last_error() << std::endl; return nullptr; }
+    return reinterpret_cast<const Color3b*>(px);
+}
 void Render::displaced(Scene& scene) { if (&scene == target) target = nullptr; }   // (already flushed by Scene::attach)
 void Render::scene_gone(Scene& scene) {
     if (&scene != target) return;

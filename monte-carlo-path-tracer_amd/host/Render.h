@@ -19,6 +19,7 @@ public:
     void flush_into(Scene& scene) override;
     void scene_gone(Scene& scene) override;
     void displaced(Scene& scene) override;
+    const Color3b* tonemapped(Scene& scene) override;
     Render(const Render&) = delete;
     Render& operator=(const Render&) = delete;
     bool ok() const { return ctx != nullptr; }

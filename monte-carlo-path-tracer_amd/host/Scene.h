@@ -18,6 +18,9 @@ public:
     virtual void scene_gone(class Scene& scene) = 0;     // `scene` is being destroyed: drop what was held for it
     virtual void displaced(class Scene& scene) = 0;      // another source took `scene` over (this one was flushed first): forget the scene --
                                                          // it may be destroyed without this source ever hearing of it again
+    // Scene::getPixelsColor of the held samples ALONE, without moving them (the Scene calls this only while its own host part is empty):
+    // a pointer to width * height tonemapped pixels that stays valid until the next call, or nullptr if the source cannot do that
+    virtual const struct Color3b* tonemapped(class Scene& scene) { (void)scene; return nullptr; }
 };
 
 class Scene {
@@ -46,5 +49,6 @@ private:
     std::unique_ptr<Pixels[]> m_Pixels;
     std::unique_ptr<std::vector<Color3b>> m_ColorsUchar;
     FilmSource* m_source = nullptr;
+    bool m_host_samples = false;                                       // m_Pixels holds something (set_Pixel / add_film): the film is host part + device part
 };
 bool write_png_rgb8(const std::string& path, int w, int h, const uint8_t* rgb);

@@ -13,6 +13,14 @@ def first_sample(step: int, rank: int, world: int, spp_per_rank: int, base: int 
     return base + (step * world + rank) * spp_per_rank
 
 
+def sample_share(step: int, rank: int, world: int, job_spp: int, base: int = 0):
+    """Strong scaling by samples: (first sample index, number of samples) of `rank` in step `step` when every step is ONE job of `job_spp`
+    samples per pixel divided over `world` ranks -- contiguous, disjoint, covering [step * job_spp, (step + 1) * job_spp) exactly; shares
+    differ by at most one sample when world does not divide job_spp."""
+    lo, hi = job_spp * rank // world, job_spp * (rank + 1) // world
+    return base + step * job_spp + lo, hi - lo
+
+
 def all_reduce_film(accum, group=None):
     """In-place sum of the film accumulator over all ranks (RCCL ring all-reduce over xGMI; per-link bound ~153 GB/s)."""
     import torch.distributed as dist

@@ -10,7 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
-def run(rank, world, port, spp, steps, out_path):
+def run(rank, world, port, spp, steps, out_path, strong=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -24,7 +24,9 @@ def run(rank, world, port, spp, steps, out_path):
     film = torch.zeros(16 * 16 * 4, dtype=torch.float32)
     for s in range(steps):
         acc = np.zeros((16, 16, 4), np.float32)
-        o.render(spp, seed=11, first_sample=mg.first_sample(s, rank, world, spp), accum=acc, threads=1)
+        # weak: every rank renders spp samples per step; strong (bench.py's default): the step is ONE job of spp samples split over the ranks
+        first, n = mg.sample_share(s, rank, world, spp) if strong else (mg.first_sample(s, rank, world, spp), spp)
+        if n: o.render(n, seed=11, first_sample=first, accum=acc, threads=1)
         local = torch.from_numpy(acc.reshape(-1).copy())
         mg.all_reduce_film(local)
         film += local

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(pkg):
     missing = [f for f in declared if not hasattr(lib, f)]
     assert not missing, missing
     assert sorted(pkg.EXPORTED_SYMBOLS) == declared           # the ctypes plumbing binds exactly the header
-    assert lib.mcpt_abi_version() == 3
+    assert lib.mcpt_abi_version() == 4
 
 
 def test_ctypes_structs_match_the_header_layout(pkg):

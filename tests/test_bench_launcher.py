@@ -21,8 +21,13 @@ def test_gpus_flag_launches_that_many_ranks():
     assert len(lines) == 1, p.stdout                                   # ONE line, from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dry"] is True
-    assert out["count_plane_ok"] is True                               # the reduced count plane holds world * spp
-    assert out["first_samples_rank0"] == [0, 16, 32]                   # rank 0 of steps 0, 1, 2 at world 2, 8 spp
+    assert out["count_plane_ok"] is True                               # the reduced count plane holds the JOB's spp: the ranks split it (strong scaling, the default)
+    assert out["scaling"] == "strong" and out["config"]["spp_per_rank"] == 4
+    assert out["first_samples_rank0"] == [0, 8, 16]                    # rank 0 of steps 0, 1, 2: every step is one 8-spp job
+    p = _run(["--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2", "--warmup", "1", "--spp", "8", "--weak"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["scaling"] == "weak" and out["count_plane_ok"] is True and out["first_samples_rank0"] == [0, 16, 32]   # rounds 1-3's mode: 8 spp per rank
 
 
 def test_world_size_mismatch_is_an_error():

@@ -24,6 +24,36 @@ def test_two_ranks_equal_one_process(pkg, orc, tmp_path):
     assert np.allclose(film[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)   # same samples, different fp32 summation order
 
 
+def test_two_ranks_split_one_job(pkg, orc, tmp_path):
+    """bench.py's default since round 4 (strong scaling): every step is ONE job of job_spp samples per pixel and the ranks split its sample
+    range (multigpu.sample_share; 5 samples over 2 ranks = 2 + 3) -- the reduced film is the single-process render of the same job."""
+    import torch.multiprocessing as mp
+    from tests import dist_worker
+    world, job_spp, steps = 2, 5, 2
+    out = str(tmp_path / "film.npy")
+    mp.spawn(dist_worker.run, args=(world, _free_port(), job_spp, steps, out, True), nprocs=world, join=True)
+    film = np.load(out)
+    o = orc.Oracle(pkg.scenes.open_box(16, 16), max_depth=4)
+    want, _, _ = o.render(job_spp * steps, seed=11, first_sample=0, threads=1)
+    assert np.array_equal(film[..., 3], want[..., 3])
+    assert np.allclose(film[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
+
+
+def test_sample_shares_cover_the_job_exactly(pkg):
+    from importlib import import_module
+    mg = import_module("mcpt_amd.multigpu")
+    for world in (1, 2, 3, 4, 8):
+        for job in (1, 5, 1024, 1000):
+            seen = []
+            for step in range(3):
+                sizes = []
+                for r in range(world):
+                    f, n = mg.sample_share(step, r, world, job)
+                    seen.extend(range(f, f + n)); sizes.append(n)
+                assert max(sizes) - min(sizes) <= 1
+            assert seen == list(range(3 * job))
+
+
 def test_sample_ranges_are_disjoint_and_contiguous(pkg):
     from importlib import import_module
     mg = import_module("mcpt_amd.multigpu")

@@ -1076,6 +1076,77 @@ def test_facade_classes_keep_the_film_on_the_device_until_it_is_read(pkg, tmp_pa
     assert [int(x) for x in line[2:5]] == [int(v) for v in (np.sqrt(m) * 255.99).astype(np.uint8)]   # Scene::getPixelsColor (Scene.cpp:25-29)
 
 
+def test_shade_early_gathers_with_miss_lanes(pkg, orc):
+    """The shade kernel requests the hit triangle's shading record, its fp64 plane and the diffuse texel EARLY (phase 1; r03 commits 7bf7f96 /
+    245810f), indexed by the hit record the trace kernel wrote.  A miss is hit.x = -1, whose masked index would be 0x0fffffff -- far outside
+    every triangle stream: an r03 A/B variant that issued such a gather for ALL lanes (before the class sort, where miss / dead lanes still
+    take part) died with a memory access fault on three scenes (gpurun_out/ab_touch.log).  The shipped requests sit behind
+    `key != K_END`, which holds only for a live slot whose extend ray this iteration's trace launch answered with a hit (index < n_tris).
+    Here the waves are MOSTLY miss lanes: (a) the camera looks out of the open side of a box -- primary rays miss or graze one wall --,
+    (b) the camera looks at the box from far away (a few pixels hit), (c) one textured triangle among untextured ones, seen from outside
+    (texel gathers for a handful of lanes of a wave, none for the rest).  Same seed against the oracle; every pixel keeps its sample count."""
+    flags = pkg.FLAG_CORRECT_SHADOW_T2
+    base = pkg.scenes.open_box(48, 48)
+    C = pkg.scenes.Camera
+    lo, hi = base.vertex.min(0), base.vertex.max(0); mid = 0.5 * (lo + hi); ext = float((hi - lo).max())
+    cam0 = base.camera
+    away = C(tuple(cam0.eye), tuple(2 * np.asarray(cam0.eye) - np.asarray(cam0.lookat)), cam0.up, cam0.fovy, 48, 48)       # looks the other way: every primary ray misses
+    far = C(tuple(np.asarray(cam0.eye) + 12 * ext * (np.asarray(cam0.eye) - mid) / np.linalg.norm(np.asarray(cam0.eye) - mid)), tuple(mid), cam0.up, cam0.fovy, 48, 48)
+    tex = pkg.scenes.value_noise_texture(16, 3)
+    mats = list(base.materials) + [pkg.scenes.Material("tex", kd=(0.5, 0.5, 0.5), map_kd="one.ppm", texture=tex)]
+    face = base.face.copy(); face[0, :, 3] = len(mats) - 1                # ONE textured triangle (half of the floor)
+    scenes = [("away", pkg.scenes.SceneData("away", base.vertex, base.normal, base.texcoord, base.face, base.materials, away)),
+              ("far", pkg.scenes.SceneData("far", base.vertex, base.normal, base.texcoord, base.face, base.materials, far)),
+              ("one-texture", pkg.scenes.SceneData("onetex", base.vertex, base.normal, base.texcoord, face, mats, cam0))]
+    for name, sc in scenes:
+        for fl in (flags, 0):                                              # the same-seed comparison in the stable mode; the default mode once for the fault alone
+            r = pkg.Renderer(sc, max_depth=5, flags=fl); r.render(16, seed=9); g = r.read_accum(); c = r.counters(); r.close()
+            assert np.all(g[..., 3] == 16) and np.isfinite(g).all(), name
+            if fl:
+                cpu, oc, _ = orc.Oracle(sc, max_depth=5, flags=fl).render(16, seed=9)
+                frac = _frac_beyond(g[..., :3] / 16, cpu[..., :3] / 16)
+                hit_share = float((cpu[..., :3].sum(-1) > 0).mean())
+                print("%s: lit pixels %.3f, pixels beyond tolerance %.3f %%, rays %d (oracle %d)" % (name, hit_share, 100 * frac, c.rays, oc["rays_primary"] + oc["rays_continuation"] + oc["rays_shadow"]))
+                assert frac <= 0.002, name
+                assert c.rays_primary == 48 * 48 * 16
+        if name == "away": assert g[..., :3].max() == 0.0                # nothing is hit, nothing is shaded
+
+
+def test_facade_getPixelsColor_runs_on_the_device(pkg, tmp_path):
+    """Round 4 (the reference's own loop, main.cpp:26-33: render(scene); getPixelsColor(); every frame): while the whole film is on the device
+    Scene::getPixelsColor hands out the DEVICE's tonemap of it (mcpt_tonemap_map: kernel + 3 B per pixel into pinned memory) instead of reading
+    16 B per pixel back and running pow on the host.  Checked through the classes: the image after the last frame equals the host path's image
+    of the same film (both are float(sqrt(clamp(mean))) * 255.99 truncated: <= 1 LSB apart, Scene.cpp:25-29), the samples are all still there
+    afterwards (5 frames -> count 5 everywhere), the film equals five one-sample mcpt_render calls, and a host-side part switches the reader back
+    to the folding path."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "monte-carlo-path-tracer_amd", "csrc"); host = os.path.join(root, "monte-carlo-path-tracer_amd", "host")
+    exe = str(tmp_path / "facade_pixels")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + host, os.path.join(root, "tests", "facade_pixels.cpp"), os.path.join(csrc, "libmcpt_host.a"), "-o", exe,
+                           "-L" + csrc, "-lmcpt_hip", "-lz", "-lpthread", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+    scene = pkg.scenes.cornell_box_small(40, 24)
+    obj = scene.write(str(tmp_path / "scene"))
+    q = lambda a: np.array([[float("%.9g" % x) for x in row] for row in a])
+    scene = pkg.scenes.SceneData(scene.name, q(scene.vertex), q(scene.normal), q(scene.texcoord), scene.face, scene.materials, scene.camera)
+    frames, depth = 5, 4
+    outs = [str(tmp_path / n) for n in ("dev.rgb", "host.rgb", "film.bin")]
+    line = subprocess.check_output([exe, obj, str(frames), str(depth)] + outs, timeout=300).decode().split()
+    assert line == ["40", "24", str(frames + 1)]
+    dev = np.fromfile(outs[0], np.uint8).reshape(24, 40, 3).astype(int); hst = np.fromfile(outs[1], np.uint8).reshape(24, 40, 3).astype(int)
+    film = np.fromfile(outs[2], np.float32).reshape(24, 40, 4)
+    assert np.all(film[..., 3] == frames)
+    assert np.abs(dev - hst).max() <= 1 and (dev != hst).mean() < 0.02
+    r = pkg.Renderer(scene, max_depth=depth, flags=pkg.FLAG_CORRECT_SHADOW_T2)
+    for f in range(frames): r.render(1, seed=21, first_sample=f)         # consecutive known-length calls: enqueued without waiting for each other
+    want = r.read_accum()
+    tm, tm2 = r.tonemap(), r.tonemap_map(); r.close()
+    assert np.allclose(film, want, rtol=2e-5, atol=1e-5)
+    assert np.array_equal(tm, tm2) and np.abs(tm.astype(int) - dev).max() <= 1
+    m = np.clip(want[..., :3] / want[..., 3:], 0, 1)
+    assert np.abs((np.sqrt(m) * 255.99).astype(np.uint8).astype(int) - dev).max() <= 1
+
+
 def test_two_triangle_scene_and_explicit_item_sizes(pkg, orc):
     """Smallest scene the builders accept (one light quad = a single leaf under an artificial root), with and without the device
     BVH flag (which falls back to the host path for <= 2 triangles), and explicit samples_per_item values around the automatic one."""
