@@ -86,7 +86,10 @@ typedef struct mcpt_scene_desc {
                                                BVH::triangles order wins (BVH.cpp:15-54 + :95-113: left, right, own triangles; `t < t2` strict) --
                                                mcpt_create then replays the reference's midpoint partition to learn that order (O(n log n) on the
                                                host).  Default: the lowest index in this library's leaf order wins (any fixed rule gives the same
-                                               image up to measure-zero ties; this flag is for tie-break-exact known-answer tests) */
+                                               image up to measure-zero ties; this flag is for tie-break-exact known-answer tests).
+                                               The tie rule lives in the production pipeline only (wavefront trace kernel, MCPT_INTEGRATOR_MIS): mcpt_create
+                                               refuses the flag with MCPT_ERR_UNSUPPORTED for MCPT_INTEGRATOR_RECURSIVE_NEE and for the cross-check megakernel
+                                               (MCPT_PIPELINE=mega), whose binary-tree traversal lets the first triangle IT tests win -- as does mcpt_probe_trace */
 
 typedef struct mcpt_opts {
     uint32_t struct_size;       /* = sizeof(mcpt_opts) */
@@ -199,7 +202,9 @@ mcpt_status mcpt_set_null_stream(mcpt_ctx* ctx);
 /* ---- function-level probes (what the parity tests call; each maps to one reference function) ---------- */
 /* BVH::hit (BVH.cpp:90-113) / BVH::has_hit (BVH.cpp:115-136) for n host rays.  origin/dir: 3 doubles per ray.
  * t1,t2: per-ray interval.  Outputs (closest): t (fp32), triangle index in face order (-1 = miss), barycentric
- * u,v.  any_hit != 0: out_tri[i] = 1/0 only. */
+ * u,v.  any_hit != 0: out_tri[i] = 1/0 only.  This is the binary-tree cross-check traversal: among triangles at EXACTLY the same distance
+ * the first one in ITS traversal order wins (neither of the production kernel's tie rules: on coincident geometry it may name another face
+ * than mcpt_probe_trace4 at the same t). */
 mcpt_status mcpt_probe_trace(mcpt_ctx* ctx, uint32_t n, const double* origin, const double* dir,
                              const double* t1, const double* t2, int any_hit,
                              float* out_t, int32_t* out_tri, float* out_u, float* out_v);

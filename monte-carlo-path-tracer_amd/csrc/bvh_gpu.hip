@@ -537,8 +537,8 @@ __global__ void c8_emit_kernel(const float4* __restrict__ n2, const unsigned cha
         }
         lo[a] = org; ebits[a] = e; scale[a] = ldexp(1.0, e);
     }
-    uint32_t q[3][2][2];
-    for (int a = 0; a < 3; a++) { q[a][0][0] = q[a][0][1] = 0xffffffffu; q[a][1][0] = q[a][1][1] = 0u; }
+    uint32_t q[3][4];                                                                // [axis][slot pair]: bytes lo, lo, hi, hi (device_scene.h: MCPT_N8_*)
+    for (int a = 0; a < 3; a++) for (int j = 0; j < 4; j++) q[a][j] = MCPT_N8_EMPTY_WORD;
     uint32_t imask = 0, p0 = 0, p1 = 0;
     C8Emit em; em.n_inner = em.n_leaf = em.leaf_tris = 0;
     for (int sl = 0; sl < 8; sl++) {
@@ -547,9 +547,8 @@ __global__ void c8_emit_kernel(const float4* __restrict__ n2, const unsigned cha
             double ql = floor(((double)kids[k].lo[a] - (double)lo[a]) / scale[a] - 1024.0 - MCPT_Q_MARGIN);
             double qh = ceil(((double)kids[k].hi[a] - (double)lo[a]) / scale[a] - 1024.0 + MCPT_Q_MARGIN);
             ql = fmin(255.0, fmax(0.0, ql)); qh = fmin(255.0, fmax(0.0, qh));
-            const int h = sl >> 2, sh = 8 * (sl & 3);
-            q[a][0][h] = (q[a][0][h] & ~(0xffu << sh)) | ((uint32_t)ql << sh);
-            q[a][1][h] = (q[a][1][h] & ~(0xffu << sh)) | ((uint32_t)qh << sh);
+            const int wj = MCPT_N8_WORD(sl);
+            q[a][wj] = (q[a][wj] & ~(0xffu << MCPT_N8_LO_SHIFT(sl)) & ~(0xffu << MCPT_N8_HI_SHIFT(sl))) | ((uint32_t)ql << MCPT_N8_LO_SHIFT(sl)) | ((uint32_t)qh << MCPT_N8_HI_SHIFT(sl));
         }
         if (kids[k].code >= 0) { imask |= 1u << sl; em.inner2[em.n_inner++] = kids[k].code; }
         else {
@@ -562,9 +561,9 @@ __global__ void c8_emit_kernel(const float4* __restrict__ n2, const unsigned cha
     float4* r = n8 + 5 * (size_t)w.rec;
     r[0] = make_float4(lo[0], lo[1], lo[2], __uint_as_float((bf16(ebits[0]) << 16) | bf16(ebits[1])));
     r[1] = make_float4(0.f, 0.f, __uint_as_float(bf16(ebits[2]) << 16), __uint_as_float(imask | (p0 << 8) | (p1 << 16) | ((p0 | p1) << 24)));
-    r[2] = make_float4(__uint_as_float(q[0][0][0]), __uint_as_float(q[0][0][1]), __uint_as_float(q[0][1][0]), __uint_as_float(q[0][1][1]));
-    r[3] = make_float4(__uint_as_float(q[1][0][0]), __uint_as_float(q[1][0][1]), __uint_as_float(q[1][1][0]), __uint_as_float(q[1][1][1]));
-    r[4] = make_float4(__uint_as_float(q[2][0][0]), __uint_as_float(q[2][0][1]), __uint_as_float(q[2][1][0]), __uint_as_float(q[2][1][1]));
+    r[2] = make_float4(__uint_as_float(q[0][0]), __uint_as_float(q[0][1]), __uint_as_float(q[0][2]), __uint_as_float(q[0][3]));
+    r[3] = make_float4(__uint_as_float(q[1][0]), __uint_as_float(q[1][1]), __uint_as_float(q[1][2]), __uint_as_float(q[1][3]));
+    r[4] = make_float4(__uint_as_float(q[2][0]), __uint_as_float(q[2][1]), __uint_as_float(q[2][2]), __uint_as_float(q[2][3]));
     emit[wi] = em; cnt_inner[wi] = em.n_inner; cnt_tris[wi] = em.leaf_tris;
 }
 

@@ -82,10 +82,16 @@ struct DevCamera {                 // Render::cast_Ray's per-frame constants hoi
 //   r[1] = u32 child_base | u32 tri_base | u32 scale_z << 16 | u32 imask | p0 << 8 | p1 << 16 | (p0 | p1) << 24
 //          slot s holds an inner child iff imask bit s: its record = child_base + popcount(imask & below(s));
 //          a leaf child of p0[s] + 2 p1[s] triangles otherwise: its first triangle = tri_base + popcount(p0 & below(s)) + 2 popcount(p1 & below(s))
-//   r[2] = x planes: u32 lo[slots 0-3] lo[4-7] hi[0-3] hi[4-7]   (byte k = slot; box = origin + (1024 + q) * scale, >= MCPT_Q_MARGIN steps outside the child's box;
-//   r[3] = y planes, r[4] = z planes                               an empty slot keeps lo = 255, hi = 0)
+//   r[2] = x planes, four u32, word j = the planes of slots 2j and 2j + 1: bytes { lo[2j], lo[2j+1], hi[2j], hi[2j+1] }  (MCPT_N8_* below; box = origin +
+//          (1024 + q) * scale, >= MCPT_Q_MARGIN steps outside the child's box; an empty slot keeps lo = 255, hi = 0).  Low and high planes of a slot pair
+//   r[3] = y planes, r[4] = z planes     share a word so that ONE v_perm_b32 with a per-ray selector picks the pair's ENTRY planes (low planes if the ray
+//          travels along +axis, high planes otherwise) and one more its EXIT planes -- no selects by direction sign (round 4; r03: 12 v_cndmask per node)
 //   Slots are OCTANT slots: bit a of s set = the child lies towards +a of the node's centre, so a ray meets the children roughly front to
 //   back in the order of s ^ (its direction octant).
+#define MCPT_N8_WORD(slot) ((slot) >> 1)                 // which of an axis record's four words holds the slot's two planes
+#define MCPT_N8_LO_SHIFT(slot) (8 * ((slot) & 1))        // bit position of its low-plane byte in that word
+#define MCPT_N8_HI_SHIFT(slot) (16 + 8 * ((slot) & 1))   // ... and of its high-plane byte
+#define MCPT_N8_EMPTY_WORD 0x0000ffffu                   // two empty slots: lo = 255, hi = 0 (an inverted box)
 struct DevScene {
     const float4* nodes;
     const float4* nodes8;

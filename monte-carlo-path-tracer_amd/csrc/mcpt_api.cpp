@@ -274,6 +274,8 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     // which pipeline this context runs is decided ONCE, here: it sets how deep a device-built binary tree may be (below) and which kernels
     // mcpt_render launches -- the two must agree, or a megakernel context could walk a tree deeper than its LDS stack
     const bool use_wavefront = [&]() { const char* pipe = std::getenv("MCPT_PIPELINE"); return !(pipe && std::string(pipe) == "mega") && o.integrator == MCPT_INTEGRATOR_MIS; }();
+    if ((o.flags & MCPT_FLAG_REFERENCE_TIE_ORDER) && !use_wavefront)
+        return fail(MCPT_ERR_UNSUPPORTED, "MCPT_FLAG_REFERENCE_TIE_ORDER needs the wavefront pipeline (MCPT_INTEGRATOR_MIS, no MCPT_PIPELINE=mega): the binary-tree kernels have no tie rule");
     int ndev = 0;
     hipError_t e = hipSuccess;
     auto check_device = [&]() -> mcpt_status {
@@ -857,6 +859,9 @@ mcpt_status mcpt_probe_trace4(mcpt_ctx* ctx, uint32_t n, const double* origin, c
         float* o4 = &ro[4 * size_t(i)]; float* d4 = &rd[4 * size_t(i)]; float* s4 = &sd[4 * size_t(i)];
         o4[3] = no_skip_f; d4[2] = 1.f; s4[2] = 1.f;
         if (i >= n) continue;
+        // a closest-hit ray with an all-zero direction stands for "this slot has no pending extend ray" (reported as a miss), like a dead slot of a
+        // job that is running out: the trace kernel must look past it
+        if (!any_hit && dir[3 * size_t(i)] == 0.0 && dir[3 * size_t(i) + 1] == 0.0 && dir[3 * size_t(i) + 2] == 0.0) continue;
         for (int k = 0; k < 3; k++) { o4[k] = float(origin[3 * size_t(i) + k] - ctx->dev.centre[k]); d4[k] = float(dir[3 * size_t(i) + k]); s4[k] = d4[k]; }
         if (any_hit) {
             s4[3] = t2[i] > 3.0e38 ? 3.0e38f : float(t2[i]);

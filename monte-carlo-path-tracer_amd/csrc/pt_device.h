@@ -117,13 +117,8 @@ DEV bool tri_accept_any(const TriTest& r, float tmin, float tmax) {
 DEV bool tri_accept_closest(const TriTest& r, float tmin, float tmax) {
     return fabsf(r.a) >= 0.00001f && r.t >= tmin && r.t < tmax && r.u >= 0.0f && r.v >= 0.0f && (1.0f - r.u - r.v) >= 0.0f;
 }
-// The same rule with a defined winner among triangles at EXACTLY the same distance: the lower (leaf-order) index.  The reference lets the
-// first one in its traversal order win (t < t2 is strict, SURVEY A-4); the 8-wide kernel tests a ray's leaf groups in an order that depends
-// on when its wave ran the leaf block, so "first tested" is not a function of the ray there -- min over (t, index) is.
-DEV bool tri_accept_closest_tie(const TriTest& r, float tmin, float tmax, int tri, int best_tri) {
-    return fabsf(r.a) >= 0.00001f && r.t >= tmin && (r.t < tmax || (r.t == tmax && tri < best_tri)) && r.u >= 0.0f && r.v >= 0.0f && (1.0f - r.u - r.v) >= 0.0f;
-}
-
+// (Exact ties: this traversal lets the first triangle it tests win.  The production kernel has a defined winner -- lowest tie rank, see the leaf
+// block of wf_trace8_kernel -- and MCPT_FLAG_REFERENCE_TIE_ORDER is refused for the kernels that traverse with this function.)
 template <bool ANY, bool COUNT>
 DEV bool bvh_traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, int skip_tri, int* stk,
                       int& hit_tri, float& hit_t, float& hit_u, float& hit_v, TravCount& tc) {

@@ -344,8 +344,8 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
             lo[a] = org; ebits[a] = e; scale[a] = std::ldexp(1.0, e);
         }
         // empty slots keep an inverted box (lo 255, hi 0): no ray interval survives it
-        uint32_t q[3][2][2];                                                         // [axis][lo / hi][slots 0-3 / 4-7]
-        for (int a = 0; a < 3; a++) { q[a][0][0] = q[a][0][1] = 0xffffffffu; q[a][1][0] = q[a][1][1] = 0u; }
+        uint32_t q[3][4];                                                            // [axis][slot pair]: bytes lo, lo, hi, hi (device_scene.h: MCPT_N8_*)
+        for (int a = 0; a < 3; a++) for (int j = 0; j < 4; j++) q[a][j] = MCPT_N8_EMPTY_WORD;
         uint32_t imask = 0, p0 = 0, p1 = 0;
         Emit& em = emit[wi];
         for (int sl = 0; sl < 8; sl++) {
@@ -354,9 +354,8 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
                 double ql = std::floor((double(kids[k].box.lo[a]) - double(lo[a])) / scale[a] - 1024.0 - MCPT_Q_MARGIN);      // (lo[] holds the stored origin now)
                 double qh = std::ceil((double(kids[k].box.hi[a]) - double(lo[a])) / scale[a] - 1024.0 + MCPT_Q_MARGIN);
                 ql = std::min(255.0, std::max(0.0, ql)); qh = std::min(255.0, std::max(0.0, qh));
-                const int h = sl >> 2, sh = 8 * (sl & 3);
-                q[a][0][h] = (q[a][0][h] & ~(0xffu << sh)) | (uint32_t(ql) << sh);
-                q[a][1][h] = (q[a][1][h] & ~(0xffu << sh)) | (uint32_t(qh) << sh);
+                uint32_t& word = q[a][MCPT_N8_WORD(sl)];
+                word = (word & ~(0xffu << MCPT_N8_LO_SHIFT(sl)) & ~(0xffu << MCPT_N8_HI_SHIFT(sl))) | (uint32_t(ql) << MCPT_N8_LO_SHIFT(sl)) | (uint32_t(qh) << MCPT_N8_HI_SHIFT(sl));
             }
             if (kids[k].code >= 0) { imask |= 1u << sl; em.inner2[em.n_inner++] = kids[k].code; }        // inner children: records in slot order
             else {                                                                   // leaf children: triangles in slot order
@@ -368,9 +367,9 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
         f4h* r = &n8[5 * size_t(w.rec)];
         r[0] = {lo[0], lo[1], lo[2], from_u32((bf16_pow2(ebits[0]) << 16) | bf16_pow2(ebits[1]))};
         r[1] = {0.f, 0.f, from_u32(bf16_pow2(ebits[2]) << 16), from_u32(imask | (p0 << 8) | (p1 << 16) | ((p0 | p1) << 24))};   // child_base / tri_base: the sweep below
-        r[2] = {from_u32(q[0][0][0]), from_u32(q[0][0][1]), from_u32(q[0][1][0]), from_u32(q[0][1][1])};   // x: lo 0-3, lo 4-7, hi 0-3, hi 4-7
-        r[3] = {from_u32(q[1][0][0]), from_u32(q[1][0][1]), from_u32(q[1][1][0]), from_u32(q[1][1][1])};   // y
-        r[4] = {from_u32(q[2][0][0]), from_u32(q[2][0][1]), from_u32(q[2][1][0]), from_u32(q[2][1][1])};   // z
+        r[2] = {from_u32(q[0][0]), from_u32(q[0][1]), from_u32(q[0][2]), from_u32(q[0][3])};   // x: slots 0-1, 2-3, 4-5, 6-7
+        r[3] = {from_u32(q[1][0]), from_u32(q[1][1]), from_u32(q[1][2]), from_u32(q[1][3])};   // y
+        r[4] = {from_u32(q[2][0]), from_u32(q[2][1]), from_u32(q[2][2]), from_u32(q[2][3])};   // z
         }
         });
         // the serial sweep: record numbers of the next level, triangle positions
@@ -429,13 +428,14 @@ std::string validate_bvh8(const HostScene& hs) {
         const f4h* Q = r + 2;
         for (int sl = 0; sl < 8; sl++) {
             const bool inner = (imask >> sl) & 1u; const uint32_t cnt = ((p0 >> sl) & 1u) + 2u * ((p1 >> sl) & 1u);
-            const uint32_t below = (1u << sl) - 1u, sh = 8u * (sl & 3);
+            const uint32_t below = (1u << sl) - 1u;
             Item ch;
             float own_lo[3], own_hi[3];
             bool inverted = false;
             for (int a = 0; a < 3; a++) {
-                const uint32_t wl = as_u32(sl < 4 ? Q[a].x : Q[a].y), wh = as_u32(sl < 4 ? Q[a].z : Q[a].w);
-                const float qlo = float((wl >> sh) & 0xffu), qhi = float((wh >> sh) & 0xffu);
+                const float* words = &Q[a].x;
+                const uint32_t word = as_u32(words[MCPT_N8_WORD(sl)]);
+                const float qlo = float((word >> MCPT_N8_LO_SHIFT(sl)) & 0xffu), qhi = float((word >> MCPT_N8_HI_SHIFT(sl)) & 0xffu);
                 if (qlo > qhi) inverted = true;
                 const float lo = org[a] + (1024.0f + qlo) * sc[a], hi = org[a] + (1024.0f + qhi) * sc[a];      // plane q = stored origin + (1024 + q) steps
                 ch.lo[a] = std::max(it.lo[a], lo); ch.hi[a] = std::min(it.hi[a], hi);

@@ -64,6 +64,18 @@ __device__ __forceinline__ uint32_t wave_first(uint32_t v) { return __builtin_am
 // store of the kernel aliases it; a vector load + readfirstlane costs a vmcnt(0) round trip instead).
 __device__ __forceinline__ uint32_t s_load_u32(const uint32_t* p) { uint32_t v; asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory"); return v; }
 
+// A per-lane select spelled as v_cndmask_b32_e64 with its lane mask as an explicit 64-bit scalar operand.  The compiler prefers the 32-bit VOP2
+// encoding, whose mask is implicitly VCC (`s_and_b64 vcc, ...` then a run of `v_cndmask_b32_e32 ..., vcc`) -- and on MI355X a run of those costs a
+// SIMD 9.7 ns per wave-instruction against 1.8 ns for the SAME select in the e64 encoding (mask in an SGPR pair or in VCC alike), 1.0 - 1.3 ns for
+// a v_mov / v_add / v_fma_f32 (tools/uarch_probe2.hip, profiles/r04_uarch_probe.txt; only an e32 select right behind the v_cmp that wrote VCC is
+// as cheap): five of them after a triangle test were a third of the leaf block's VALU time.
+__device__ __forceinline__ uint64_t wf_mask(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ uint32_t wf_sel(uint64_t mask, uint32_t if_set, uint32_t if_clear) {
+    uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask)); return r;
+}
+__device__ __forceinline__ float wf_sel(uint64_t mask, float if_set, float if_clear) { return __uint_as_float(wf_sel(mask, __float_as_uint(if_set), __float_as_uint(if_clear))); }
+__device__ __forceinline__ int wf_sel(uint64_t mask, int if_set, int if_clear) { return (int)wf_sel(mask, (uint32_t)if_set, (uint32_t)if_clear); }
+
 // ====================================================================================================== shade
 // Branch-sorted shading.  The reference assembles a different lobe set per material (BSDF.cpp:95-107) and a path may end at
 // every vertex (miss, Russian roulette, depth), so lanes that simply own "their" slot diverge: measured 0.48 VALU lane utilisation
@@ -643,7 +655,8 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     uint32_t c_next = wave_id * batch, c_end = c_next + batch;
     take_chunk(c_next++);
 
-    bool have = false, any = false, blocked = false;
+    bool have = false, any = false;
+    uint32_t blocked = 0u;                                             // any-hit rays: an occluder was found (0 / 1; updated by selects on SGPR masks, see wf_sel)
     uint32_t slot = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     float idx = 0, idy = 0, idz = 0, tmax = 0;
@@ -651,6 +664,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     // cur = the group on top of the lane's stack, held in registers: .y & 0xff != 0 -> inner group G; .y != 0 otherwise -> a leaf group
     // waiting for the parking place; .y == 0 -> bottom of the stack (the ray is finished once T is empty too).  T = the parked leaf group.
     uint32_t cur_x = 0, cur_y = 0, t_x = 0, t_y = 0, oct = 0;
+    uint32_t snx = 0, sfx = 0, sny = 0, sfy = 0, snz = 0, sfz = 0;     // v_perm_b32 selectors of the ray's entry / exit plane bytes per axis (inner_consume)
     int sp = 1;
     int htri = -1; float hu = 0, hv = 0;
     uint32_t hrank = 0;                                                // tie rank of the best hit so far (closest-hit rays)
@@ -701,22 +715,16 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         const uint32_t sxy = __float_as_uint(R0.w), masks = __float_as_uint(R1.w);
         const float ax = __uint_as_float(sxy & 0xffff0000u) * idx, ay = __uint_as_float(sxy << 16) * idy, az = R1.z * idz;   // (R1.z: the builders leave its low half zero)
         const float bx = fmaf(R0.x, idx, nox), by = fmaf(R0.y, idy, noy), bz = fmaf(R0.z, idz, noz);   // R0.xyz = the frame origin LESS 1024 steps: plane q lies at R0 + (1024 + q) step (WF8_CHILD)
-        const bool ngx = idx < 0.0f, ngy = idy < 0.0f, ngz = idz < 0.0f;
-        // entry planes = the low planes on axes the ray travels along positively, the high planes otherwise
-        const uint32_t xl0 = __float_as_uint(R2.x), xl1 = __float_as_uint(R2.y), xh0 = __float_as_uint(R2.z), xh1 = __float_as_uint(R2.w);
-        const uint32_t yl0 = __float_as_uint(R3.x), yl1 = __float_as_uint(R3.y), yh0 = __float_as_uint(R3.z), yh1 = __float_as_uint(R3.w);
-        const uint32_t zl0 = __float_as_uint(R4.x), zl1 = __float_as_uint(R4.y), zh0 = __float_as_uint(R4.z), zh1 = __float_as_uint(R4.w);
-        const uint32_t nx0 = ngx ? xh0 : xl0, nx1 = ngx ? xh1 : xl1, fx0 = ngx ? xl0 : xh0, fx1 = ngx ? xl1 : xh1;
-        const uint32_t ny0 = ngy ? yh0 : yl0, ny1 = ngy ? yh1 : yl1, fy0 = ngy ? yl0 : yh0, fy1 = ngy ? yl1 : yh1;
-        const uint32_t nz0 = ngz ? zh0 : zl0, nz1 = ngz ? zh1 : zl1, fz0 = ngz ? zl0 : zh0, fz1 = ngz ? zl1 : zh1;
+        // Word j of an axis record = the planes of slots 2j, 2j + 1 as bytes { lo, lo, hi, hi } (device_scene.h).  One v_perm_b32 turns the pair's
+        // ENTRY planes into the fp16 pair {1024 + q, 1024 + q} and another its EXIT planes; which bytes are "entry" is the ray's business: the
+        // selectors sn* / sf* (low bytes for an axis the ray travels along positively, high bytes otherwise) are made once per ray at the refill.
+        // (r03 selected whole plane words with 12 v_cndmask per node.)
         uint32_t m = 0u;
-        // bytes (2p, 2p + 1) of a plane word -> the fp16 pair {1024 + q, 1024 + q}
-        auto h_lo = [&](uint32_t w) __attribute__((always_inline)) { const uint32_t r = __builtin_amdgcn_perm(k64, w, 0x04010400u); wf_h2 h; __builtin_memcpy(&h, &r, 4); return h; };
-        auto h_hi = [&](uint32_t w) __attribute__((always_inline)) { const uint32_t r = __builtin_amdgcn_perm(k64, w, 0x04030402u); wf_h2 h; __builtin_memcpy(&h, &r, 4); return h; };
-        { const wf_h2 NX = h_hi(nx1), FX = h_hi(fx1), NY = h_hi(ny1), FY = h_hi(fy1), NZ = h_hi(nz1), FZ = h_hi(fz1); WF8_CHILD(7, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(6, NX, FX, NY, FY, NZ, FZ) }
-        { const wf_h2 NX = h_lo(nx1), FX = h_lo(fx1), NY = h_lo(ny1), FY = h_lo(fy1), NZ = h_lo(nz1), FZ = h_lo(fz1); WF8_CHILD(5, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(4, NX, FX, NY, FY, NZ, FZ) }
-        { const wf_h2 NX = h_hi(nx0), FX = h_hi(fx0), NY = h_hi(ny0), FY = h_hi(fy0), NZ = h_hi(nz0), FZ = h_hi(fz0); WF8_CHILD(3, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(2, NX, FX, NY, FY, NZ, FZ) }
-        { const wf_h2 NX = h_lo(nx0), FX = h_lo(fx0), NY = h_lo(ny0), FY = h_lo(fy0), NZ = h_lo(nz0), FZ = h_lo(fz0); WF8_CHILD(1, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(0, NX, FX, NY, FY, NZ, FZ) }
+        auto pair16 = [&](float w, uint32_t sel) __attribute__((always_inline)) { const uint32_t r = __builtin_amdgcn_perm(k64, __float_as_uint(w), sel); wf_h2 h; __builtin_memcpy(&h, &r, 4); return h; };
+        { const wf_h2 NX = pair16(R2.w, snx), FX = pair16(R2.w, sfx), NY = pair16(R3.w, sny), FY = pair16(R3.w, sfy), NZ = pair16(R4.w, snz), FZ = pair16(R4.w, sfz); WF8_CHILD(7, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(6, NX, FX, NY, FY, NZ, FZ) }
+        { const wf_h2 NX = pair16(R2.z, snx), FX = pair16(R2.z, sfx), NY = pair16(R3.z, sny), FY = pair16(R3.z, sfy), NZ = pair16(R4.z, snz), FZ = pair16(R4.z, sfz); WF8_CHILD(5, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(4, NX, FX, NY, FY, NZ, FZ) }
+        { const wf_h2 NX = pair16(R2.y, snx), FX = pair16(R2.y, sfx), NY = pair16(R3.y, sny), FY = pair16(R3.y, sfy), NZ = pair16(R4.y, snz), FZ = pair16(R4.y, sfz); WF8_CHILD(3, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(2, NX, FX, NY, FY, NZ, FZ) }
+        { const wf_h2 NX = pair16(R2.x, snx), FX = pair16(R2.x, sfx), NY = pair16(R3.x, sny), FY = pair16(R3.x, sfy), NZ = pair16(R4.x, snz), FZ = pair16(R4.x, sfz); WF8_CHILD(1, NX, FX, NY, FY, NZ, FZ) WF8_CHILD(0, NX, FX, NY, FY, NZ, FZ) }
         const uint32_t leaf_slots = masks >> 24;                 // = p0 | p1, stored by the builder
 #ifndef WF_SCHED_STATS
         if (COUNT) n_box += (uint32_t)__popc((masks & 0xffu) | leaf_slots);
@@ -725,9 +733,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
         const uint32_t ml = m & leaf_slots;                      // hit leaf children (an empty slot's inverted box cannot be hit; the mask keeps that exact)
         if (order_matters) mi = s_perm[(oct << 8) | mi];         // bit j <- slot j ^ oct (wave-uniform branch; identity for any-hit rays, whose oct is 0)
         const uint32_t gn_y = (masks << 8) | mi;                 // (the count planes ride along in bits 16-31; every use masks them off)
-        const uint32_t tn_y = ml ? ((masks & 0x00ffff00u) | (ml << 24)) : 0u;
+        const uint32_t tn_y = (masks & 0x00ffff00u) | (ml << 24);    // the node's leaf group -- meaningful only if ml != 0 (no select: a select on VCC is the dearest VALU instruction here, see wf_sel)
         const bool keep_cur = (cur_y & 0xffu) != 0u;             // siblings of the child just taken are still pending
-        const bool t_park = tn_y != 0u && t_y == 0u, t_push = tn_y != 0u && t_y != 0u;
+        const bool t_park = ml != 0u && t_y == 0u, t_push = ml != 0u && t_y != 0u;
         v2u e_cur, e_tn; e_cur.x = cur_x; e_cur.y = cur_y; e_tn.x = __float_as_uint(R1.y); e_tn.y = tn_y;
         if (sp + 2 <= WF8_LDS_STACK) {
             // common case, branch-free: store both candidates, advance the stack pointer only past the real ones
@@ -777,7 +785,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 #endif
             if (have && cur_y == 0u && t_y == 0u) {                      // finished: write the result back
                 if (any) {
-                    if (blocked) st_s(reinterpret_cast<uint32_t*>(&pool.nee[slot]) + 3, 1u);
+                    if (blocked != 0u) st_s(reinterpret_cast<uint32_t*>(&pool.nee[slot]) + 3, 1u);
                 } else {
                     st_s(&pool.hit[slot], make_float4(__int_as_float(htri), hu, hv, tmax));
                 }
@@ -823,18 +831,24 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                         const float tiny = 1e-30f;
                         // v_rcp_f32 (1 ulp) instead of the IEEE divide sequence (~10 VALU issues each, executed for the ~19 lanes a refill feeds):
                         // the child boxes carry ~16 ulp of padding for exactly this kind of rounding in the slab arithmetic
-                        idx = __builtin_amdgcn_rcpf(fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
-                        idy = __builtin_amdgcn_rcpf(fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
-                        idz = __builtin_amdgcn_rcpf(fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+                        idx = __builtin_amdgcn_rcpf(wf_sel(wf_mask(fabsf(d.x) > tiny), d.x, copysignf(tiny, d.x)));
+                        idy = __builtin_amdgcn_rcpf(wf_sel(wf_mask(fabsf(d.y) > tiny), d.y, copysignf(tiny, d.y)));
+                        idz = __builtin_amdgcn_rcpf(wf_sel(wf_mask(fabsf(d.z) > tiny), d.z, copysignf(tiny, d.z)));
                         nox = -o.x * idx; noy = -o.y * idy; noz = -o.z * idz;
+                        // bytes {0, 1} of a plane word are a slot pair's low planes, {2, 3} its high planes; 0x64 = the fp16 exponent byte from k64
+                        constexpr uint32_t SEL_LO = 0x04010400u, SEL_HI = 0x04030402u;
+                        const uint64_t mnx = wf_mask(idx < 0.0f), mny = wf_mask(idy < 0.0f), mnz = wf_mask(idz < 0.0f);
+                        snx = wf_sel(mnx, SEL_HI, SEL_LO); sfx = wf_sel(mnx, SEL_LO, SEL_HI);
+                        sny = wf_sel(mny, SEL_HI, SEL_LO); sfy = wf_sel(mny, SEL_LO, SEL_HI);
+                        snz = wf_sel(mnz, SEL_HI, SEL_LO); sfz = wf_sel(mnz, SEL_LO, SEL_HI);
                         // the visiting order only matters to closest-hit rays (Render.cpp:125 asks whether the light is visible at all):
                         // any-hit rays keep octant 0, i.e. slot order -- and a wave that carries no closest-hit ray skips the permutation
-                        oct = any ? 0u : ((idx < 0.0f ? 1u : 0u) | (idy < 0.0f ? 2u : 0u) | (idz < 0.0f ? 4u : 0u));
+                        oct = wf_sel(wf_mask(any), 0u, wf_sel(mnx, 1u, 0u) | wf_sel(mny, 2u, 0u) | wf_sel(mnz, 4u, 0u));
                         v2u bottom; bottom.x = 0u; bottom.y = 0u;
                         stk[0] = bottom; sp = 1;
                         cur_x = 0u; cur_y = 1u;                          // "child 0 of base 0, no inner siblings": the root
                         t_x = 0u; t_y = 0u;
-                        hu = 0.f; hv = 0.f; blocked = false;
+                        hu = 0.f; hv = 0.f; blocked = 0u;
                         have = true;
                     }
                 }
@@ -855,7 +869,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 const uint32_t cnt = ((t_y >> (8u + s)) & 1u) + 2u * ((t_y >> (16u + s)) & 1u);
                 t_y &= ~(1u << (24u + s));
                 if ((t_y >> 24) == 0u) t_y = 0u;
-                bool done = false;
+                uint64_t done = 0ull;                                    // lane mask: any-hit rays that found their occluder in this leaf
                 // Both acceptance rules (Triangle::hit / Triangle::isIntersect, see tri_accept_* in pt_device.h) as ONE predicate and the hit-state
                 // update as four selects: spelled with short-circuit `&&` and `if` the compiler built a branch per term and copied the hit state
                 // (tmax, triangle, u, v) at every join -- ~12 of ~64 VALU issues per triangle.  `u <= 1` of the any-hit rule is implied by
@@ -863,7 +877,8 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 // KIND: 1 = every lane of this execution carries a closest-hit ray, 2 = every lane an any-hit ray, 0 = mixed.  A wave works through
                 // chunks of one kind (the extend rays come first in the list), so the mixed form is rare; the uniform forms drop the other rule's
                 // compares and -- any-hit -- all four selects.
-                auto leaf_test = [&](auto kind_c, const float4 v0, const float4 e1, const float4 e2, const int ti, const bool use) __attribute__((always_inline)) {
+                // The verdicts live as LANE MASKS in SGPR pairs (accept, update, occluded) and every per-lane consequence is a select on such a mask.
+                auto leaf_test = [&](auto kind_c, const float4 v0, const float4 e1, const float4 e2, const int ti, const bool use, const uint64_t skip_lanes) __attribute__((always_inline)) {
                     constexpr int kind = decltype(kind_c)::value;
                     const bool is_any = kind == 2 ? true : (kind == 1 ? false : any);
                     const TriTest r = tri_test(v0, e1, e2, o, d);
@@ -874,13 +889,16 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     const uint32_t rank = __float_as_uint(v0.w) & HIT_TRI_MASK;
                     const bool tie_win = (r.t == tmax) & (rank < hrank);
                     const bool t_ok = (r.t >= 1e-4f) & (is_any ? (r.t <= tmax) : ((r.t < tmax) | tie_win));
-                    const bool acc = use & a_ok & uv_ok & t_ok;
-                    const bool upd = acc & !is_any;
-                    tmax = upd ? r.t : tmax; hu = upd ? r.u : hu; hv = upd ? r.v : hv;
-                    htri = upd ? (ti | (__float_as_int(v0.w) & ~HIT_TRI_MASK)) : htri;   // v0.w = lobe class << 28 | tie rank
-                    hrank = upd ? rank : hrank;
-                    blocked = blocked | (acc & is_any);
-                    return acc & is_any;
+                    const uint64_t acc = wf_mask(use & a_ok & uv_ok & t_ok) & ~skip_lanes;
+                    const uint64_t m_any = kind == 2 ? ~0ull : (kind == 1 ? 0ull : wf_mask(any));
+                    const uint64_t upd = acc & ~m_any, occ = acc & m_any;
+                    if (kind != 2) {
+                        tmax = wf_sel(upd, r.t, tmax); hu = wf_sel(upd, r.u, hu); hv = wf_sel(upd, r.v, hv);
+                        htri = wf_sel(upd, ti | (__float_as_int(v0.w) & ~HIT_TRI_MASK), htri);   // v0.w = lobe class << 28 | tie rank
+                        hrank = wf_sel(upd, rank, hrank);
+                    }
+                    blocked = wf_sel(occ, 1u, blocked);
+                    return occ;
                 };
                 constexpr bool one_pair = MCPT_LEAF_MAX <= 2;            // a leaf holds at most MCPT_LEAF_MAX triangles: with two the pair loop is one pass
                 uint32_t i = 0;
@@ -900,16 +918,16 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 #endif
                     const uint64_t m_kind = __ballot(any), m_here = __ballot(true);
                     if (m_kind == m_here) {
-                        done = leaf_test(WfKind<2>{}, v0a, e1a, e2a, ta, use_a);
-                        if (__ballot(use_b) != 0) done = done | leaf_test(WfKind<2>{}, v0b, e1b, e2b, tb, use_b & !done);
+                        done |= leaf_test(WfKind<2>{}, v0a, e1a, e2a, ta, use_a, done);
+                        if (__ballot(use_b) != 0) done |= leaf_test(WfKind<2>{}, v0b, e1b, e2b, tb, use_b, done);
                     } else {
-                        done = leaf_test(WfKind<0>{}, v0a, e1a, e2a, ta, use_a);
-                        if (__ballot(use_b) != 0) done = done | leaf_test(WfKind<0>{}, v0b, e1b, e2b, tb, use_b & !done);
+                        done |= leaf_test(WfKind<0>{}, v0a, e1a, e2a, ta, use_a, done);
+                        if (__ballot(use_b) != 0) done |= leaf_test(WfKind<0>{}, v0b, e1b, e2b, tb, use_b, done);
                     }
                     i += 2;
-                } while (!one_pair && i < cnt && !done);
-                if (done) { cur_y = 0u; t_y = 0u; }                      // any-hit: stop at the first occluder
-                else WF8_PARK()                                          // the group is worked off and another one was waiting on top of the stack
+                } while (!one_pair && i < cnt && ((done >> lane) & 1ull) == 0ull);
+                cur_y = wf_sel(done, 0u, cur_y); t_y = wf_sel(done, 0u, t_y);   // any-hit: stop at the first occluder
+                WF8_PARK()                                               // the group is worked off and another one was waiting on top of the stack (never true for a lane that just stopped: its cur_y is 0)
             }
             WF_TICK(t_leaf)
         }

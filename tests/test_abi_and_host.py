@@ -68,6 +68,23 @@ def test_device_bvh_build_flag_also_needs_a_device(pkg):
     assert "status 2" in str(e.value)
 
 
+def test_reference_tie_order_flag_is_refused_where_no_kernel_implements_it(pkg):
+    """MCPT_FLAG_REFERENCE_TIE_ORDER (and the defined tie winner in general) lives in the production trace kernel only: a context whose kernels
+    traverse the binary tree -- the recursive integrator, the cross-check megakernel -- refuses the flag (MCPT_ERR_UNSUPPORTED = status 6)
+    instead of silently ignoring it.  Decided before any device is touched: runs without a GPU."""
+    scene = pkg.scenes.open_box(8, 8)
+    with pytest.raises(pkg.McptError) as e:
+        pkg.Renderer(scene, integrator=pkg.INTEGRATOR_RECURSIVE_NEE, flags=pkg.FLAG_REFERENCE_TIE_ORDER)
+    assert "status 6" in str(e.value) and "tie" in str(e.value).lower()
+    os.environ["MCPT_PIPELINE"] = "mega"
+    try:
+        with pytest.raises(pkg.McptError) as e:
+            pkg.Renderer(scene, flags=pkg.FLAG_REFERENCE_TIE_ORDER)
+        assert "status 6" in str(e.value)
+    finally:
+        os.environ.pop("MCPT_PIPELINE", None)
+
+
 def test_product_library_does_not_reference_the_oracle(pkg):
     """The shipped library must not link, load or embed anything under oracle/."""
     out = subprocess.check_output(["ldd", pkg.LIB_PATH]).decode()

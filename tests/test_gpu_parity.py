@@ -330,6 +330,29 @@ def test_probe_trace4_hot_kernel_vs_reference(pkg, paths, tree, grid):
     _same_numbers(t4[same], t2_[same], u4[same], u2[same], v4[same], v2[same])
 
 
+def test_probe_trace4_sparse_ray_lists(pkg, paths):
+    """Slots without a pending extend ray (dead / draining paths: bit 0 of ray_d.w clear) sit between live ones in the trace kernel's ray list
+    whenever a job is running out -- the last iterations of every job, all but the first of a one-sample-per-pixel call.  mcpt_probe_trace4
+    leaves such holes where a ray's direction is all-zero: the reference's 4 000 rays with holes punched in -- one ray in 17 left, every
+    second ray, whole 256-slot blocks empty, one block with a single ray -- must come back with the answers the full list gives, ray for ray
+    (same triangle, same t / u / v bit for bit: the traversal of a ray does not depend on its neighbours), and the holes as misses.
+    (Round 4 also tried handing the kernel COMPACTED lists for such blocks: no gain on a one-sample call -- its launches are bound by their
+    longest ray, not by the holes -- and +2.5 % on the steady state; dropped)"""
+    r = pkg.Renderer(pkg.scenes.cornell_box_small(64, 64))
+    o, d = paths["cs_ray_o"], paths["cs_ray_d"]
+    n = len(o)
+    t0, tri0, u0, v0 = r.probe_trace4(o, d)
+    idx = np.arange(n)
+    patterns = {"1 in 17": idx % 17 == 3, "every second": idx % 2 == 0, "blocks 1, 2, 5 empty": ~np.isin(idx // 256, (1, 2, 5)),
+                "one ray in block 3": (idx // 256 != 3) | (idx == 3 * 256 + 77), "only block 0": idx < 256, "three rays": np.isin(idx, (5, 1000, 3999))}
+    for name, keep in patterns.items():
+        dd = d.copy(); dd[~keep] = 0.0
+        t, tri, u, v = r.probe_trace4(o, dd)
+        assert np.all(tri[~keep] == -1), name
+        assert np.array_equal(tri[keep], tri0[keep]) and np.array_equal(t[keep], t0[keep]) and np.array_equal(u[keep], u0[keep]) and np.array_equal(v[keep], v0[keep]), name
+    r.close()
+
+
 def test_probe_hit_shade_vs_reference(pkg, paths):
     """Triangle::hit's shading record (Triangle.cpp:35-46, 68-76: interpolated + normalised vertex normal, interpolated uv, front flag) on
     the reference's own 4 000 rays: the production trace kernel finds the hit (mcpt_probe_trace4), load_hit_shade -- the function the shade
@@ -1131,7 +1154,7 @@ def test_facade_getPixelsColor_runs_on_the_device(pkg, tmp_path):
     scene = pkg.scenes.SceneData(scene.name, q(scene.vertex), q(scene.normal), q(scene.texcoord), scene.face, scene.materials, scene.camera)
     frames, depth = 5, 4
     outs = [str(tmp_path / n) for n in ("dev.rgb", "host.rgb", "film.bin")]
-    line = subprocess.check_output([exe, obj, str(frames), str(depth)] + outs, timeout=300).decode().split()
+    line = subprocess.check_output([exe, obj, str(frames), str(depth)] + outs, timeout=300).decode().split("\n")[-2].split()   # (the loader prints "[Model] <path>" first, like the reference)
     assert line == ["40", "24", str(frames + 1)]
     dev = np.fromfile(outs[0], np.uint8).reshape(24, 40, 3).astype(int); hst = np.fromfile(outs[1], np.uint8).reshape(24, 40, 3).astype(int)
     film = np.fromfile(outs[2], np.float32).reshape(24, 40, 4)
@@ -1203,18 +1226,22 @@ def test_exact_ties_follow_the_reference_order_when_asked(pkg):
 
 
 # ------------------------------------------------------------------------------------------------ the bench configurations themselves
-@pytest.mark.parametrize("tag", ["c2", "c3", "c4s"])
+@pytest.mark.parametrize("tag", ["c2", "c3", "c4s", "c4", "c5w"])
 def test_full_size_block_statistics_vs_reference(pkg, tag):
     """The BENCH configurations at their own resolution against the REAL reference (tests/golden/ref_fullsize_<tag>.npz, written by
-    make_golden.py from oracle/_ref: 8 batches x 16 spp = 128 spp, as 8x8-pixel block means with their batch-to-batch variance):
-    c2 = S-cornell 800x800 depth 8, c3 = S-veach 1280x720 unbounded, c4s = S-bath (93 k triangles) 1920x1080 unbounded.  The GPU renders
-    32 batches x 32 spp, so the statistic z = |difference of block means| / sqrt(var_gpu + var_ref) is carried by the reference's variance
-    estimate from 8 batches: Student t with 7 degrees of freedom -- 0.52 % of blocks beyond 4 and a median |z| of 0.71 are what
-    IDENTICAL renderers give.  Asserted: image mean within 1 %, at most 1 % of blocks beyond 4, median |z| in [0.6, 0.85]."""
+    make_golden.py from oracle/_ref: 8 batches x 16 spp = 128 spp -- c4 / c5w: 8 x 8 = 64 spp --, as 8x8-pixel block means with their
+    batch-to-batch variance): c2 = S-cornell 800x800 depth 8, c3 = S-veach 1280x720 unbounded, c4s = S-bath (93 k triangles) 1920x1080
+    unbounded; round 4: c4 = BASELINE configs[3] with its REAL triangle count (S-bath 0.59 M triangles, 1920x1080, unbounded) and c5w = the
+    4.05 M-triangle scene of configs[4] at depth 16 through a 480x270 film of the same view (the reference's regex OBJ parser and its
+    midpoint BVH over 4 M triangles: paid once, in the build container).  The GPU renders 32 batches x 32 spp, so the statistic
+    z = |difference of block means| / sqrt(var_gpu + var_ref) is carried by the reference's variance estimate from 8 batches: Student t with
+    7 degrees of freedom -- 0.52 % of blocks beyond 4 and a median |z| of 0.71 are what IDENTICAL renderers give.  Asserted: image mean
+    within 1 %, at most 0.8 % of blocks beyond 4 (r03: 1 %; measured 0.26 - 0.41 %), median |z| in [0.6, 0.85]."""
     path = os.path.join(G, "ref_fullsize_%s.npz" % tag)
     if not os.path.exists(path): pytest.skip(path + " not generated")
     g = _npz("ref_fullsize_%s.npz" % tag)
-    name, kw, (w, h) = {"c2": ("cornell-box", {}, (800, 800)), "c3": ("veach-mis", {}, (1280, 720)), "c4s": ("bathroom2", {"detail": 64}, (1920, 1080))}[tag]
+    name, kw, (w, h) = {"c2": ("cornell-box", {}, (800, 800)), "c3": ("veach-mis", {}, (1280, 720)), "c4s": ("bathroom2", {"detail": 64}, (1920, 1080)),
+                        "c4": ("bathroom2", {"detail": 160}, (1920, 1080)), "c5w": ("bathroom2", {"detail": 420}, (480, 270))}[tag]
     r = pkg.Renderer(pkg.scenes.SCENES[name](w, h, **kw), max_depth=int(g["depth"]))
     B, S, b = 32, 32, int(g["block"])
     bm = []
@@ -1230,7 +1257,7 @@ def test_full_size_block_statistics_vs_reference(pkg, tag):
     print("%s: image mean gpu %s reference %s (rel %s); blocks beyond 4 sigma %.3f %%, beyond 3 sigma %.3f %% (t7: 0.52 / 1.99), median |z| %.3f (t7: 0.711)" % (
         tag, gm.mean((0, 1)), rm.mean((0, 1)), rel, 100 * f4, 100 * f3, med))
     assert np.all(np.abs(rel) <= 0.01)
-    assert f4 <= 0.01 and 0.6 <= med <= 0.85
+    assert f4 <= 0.008 and 0.6 <= med <= 0.85
 
 
 def test_c1_own_size_vs_oracle(pkg, orc):

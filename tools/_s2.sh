@@ -15,3 +15,5 @@ for f in glob.glob("gpurun_out/calib/**/*counter_collection.csv", recursive=True
 PY
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "miss_lanes or facade or frame_by_frame or sample_split or stream_ordered or tonemap or clone or random_walk or two_threads" > gpurun_out/r04_pytest_b.log 2>&1; tail -5 gpurun_out/r04_pytest_b.log
 timeout -k 10 300 tools/frame_loop.sh 300 trace > gpurun_out/r04_frame_loop.log 2>&1; cat gpurun_out/r04_frame_loop.log
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r04_pytest_c.log 2>&1; tail -5 gpurun_out/r04_pytest_c.log
+tools/ab.sh 512 cornell-box default > gpurun_out/r04_ab_sel.log 2>&1; MCPT_DEPTH=16 tools/ab.sh 32 bathroom:420 default >> gpurun_out/r04_ab_sel.log 2>&1; tools/ab.sh 64 bathroom:160 default >> gpurun_out/r04_ab_sel.log 2>&1; cat gpurun_out/r04_ab_sel.log

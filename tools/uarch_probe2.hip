@@ -43,6 +43,30 @@
     X(FMA_F64,   "v_fma_f64 %12, %12, %16, %16",          "v_fma_f64 %13, %13, %16, %16", "v_fma_f64 %12, %12, %16, %16", "v_fma_f64 %13, %13, %16, %16", "v_fma_f64 %12, %12, %16, %16", "v_fma_f64 %13, %13, %16, %16", "v_fma_f64 %12, %12, %16, %16", "v_fma_f64 %13, %13, %16, %16") \
     X(RCP,       "v_rcp_f32 %0, %0",                      "v_rcp_f32 %1, %1", "v_rcp_f32 %2, %2", "v_rcp_f32 %3, %3", "v_rcp_f32 %4, %4", "v_rcp_f32 %5, %5", "v_rcp_f32 %6, %6", "v_rcp_f32 %7, %7") \
     X(MBCNT,     "v_mbcnt_lo_u32_b32 %0, %8, %0",        "v_mbcnt_lo_u32_b32 %1, %8, %1", "v_mbcnt_lo_u32_b32 %2, %8, %2", "v_mbcnt_lo_u32_b32 %3, %8, %3", "v_mbcnt_lo_u32_b32 %4, %8, %4", "v_mbcnt_lo_u32_b32 %5, %8, %5", "v_mbcnt_lo_u32_b32 %6, %8, %6", "v_mbcnt_lo_u32_b32 %7, %8, %7") \
+    X(CND_E64VCC,"v_cndmask_b32_e64 %0, %0, %14, vcc",     "v_cndmask_b32_e64 %1, %1, %14, vcc", "v_cndmask_b32_e64 %2, %2, %14, vcc", "v_cndmask_b32_e64 %3, %3, %14, vcc", "v_cndmask_b32_e64 %4, %4, %14, vcc", "v_cndmask_b32_e64 %5, %5, %14, vcc", "v_cndmask_b32_e64 %6, %6, %14, vcc", "v_cndmask_b32_e64 %7, %7, %14, vcc") \
+    X(CMP_CND,   "v_cmp_le_f32 vcc, %0, %14\n v_cndmask_b32 %0, %0, %15, vcc", "v_cmp_le_f32 vcc, %1, %14\n v_cndmask_b32 %1, %1, %15, vcc", "v_cmp_le_f32 vcc, %2, %14\n v_cndmask_b32 %2, %2, %15, vcc", "v_cmp_le_f32 vcc, %3, %14\n v_cndmask_b32 %3, %3, %15, vcc", "v_cmp_le_f32 vcc, %4, %14\n v_cndmask_b32 %4, %4, %15, vcc", "v_cmp_le_f32 vcc, %5, %14\n v_cndmask_b32 %5, %5, %15, vcc", "v_cmp_le_f32 vcc, %6, %14\n v_cndmask_b32 %6, %6, %15, vcc", "v_cmp_le_f32 vcc, %7, %14\n v_cndmask_b32 %7, %7, %15, vcc") \
+    X(CMP_CND64, "v_cmp_le_f32 %10, %0, %14\n v_cndmask_b32 %0, %0, %15, %10", "v_cmp_le_f32 %10, %1, %14\n v_cndmask_b32 %1, %1, %15, %10", "v_cmp_le_f32 %10, %2, %14\n v_cndmask_b32 %2, %2, %15, %10", "v_cmp_le_f32 %10, %3, %14\n v_cndmask_b32 %3, %3, %15, %10", "v_cmp_le_f32 %10, %4, %14\n v_cndmask_b32 %4, %4, %15, %10", "v_cmp_le_f32 %10, %5, %14\n v_cndmask_b32 %5, %5, %15, %10", "v_cmp_le_f32 %10, %6, %14\n v_cndmask_b32 %6, %6, %15, %10", "v_cmp_le_f32 %10, %7, %14\n v_cndmask_b32 %7, %7, %15, %10") \
+    X(SUB_F32,   "v_sub_f32 %0, %0, %14",                  "v_sub_f32 %1, %1, %14", "v_sub_f32 %2, %2, %14", "v_sub_f32 %3, %3, %14", "v_sub_f32 %4, %4, %14", "v_sub_f32 %5, %5, %14", "v_sub_f32 %6, %6, %14", "v_sub_f32 %7, %7, %14") \
+    X(MIN_F32,   "v_min_f32 %0, %0, %14",                  "v_min_f32 %1, %1, %14", "v_min_f32 %2, %2, %14", "v_min_f32 %3, %3, %14", "v_min_f32 %4, %4, %14", "v_min_f32 %5, %5, %14", "v_min_f32 %6, %6, %14", "v_min_f32 %7, %7, %14") \
+    X(MED3_F32,  "v_med3_f32 %0, %0, %14, %15",            "v_med3_f32 %1, %1, %14, %15", "v_med3_f32 %2, %2, %14, %15", "v_med3_f32 %3, %3, %14, %15", "v_med3_f32 %4, %4, %14, %15", "v_med3_f32 %5, %5, %14, %15", "v_med3_f32 %6, %6, %14, %15", "v_med3_f32 %7, %7, %14, %15") \
+    X(ALIGNBIT,  "v_alignbit_b32 %0, %0, %8, 31",          "v_alignbit_b32 %1, %1, %8, 31", "v_alignbit_b32 %2, %2, %8, 31", "v_alignbit_b32 %3, %3, %8, 31", "v_alignbit_b32 %4, %4, %8, 31", "v_alignbit_b32 %5, %5, %8, 31", "v_alignbit_b32 %6, %6, %8, 31", "v_alignbit_b32 %7, %7, %8, 31") \
+    X(XOR,       "v_xor_b32 %0, %0, %8",                   "v_xor_b32 %1, %1, %8", "v_xor_b32 %2, %2, %8", "v_xor_b32 %3, %3, %8", "v_xor_b32 %4, %4, %8", "v_xor_b32 %5, %5, %8", "v_xor_b32 %6, %6, %8", "v_xor_b32 %7, %7, %8") \
+    X(OR,        "v_or_b32 %0, %0, %8",                    "v_or_b32 %1, %1, %8", "v_or_b32 %2, %2, %8", "v_or_b32 %3, %3, %8", "v_or_b32 %4, %4, %8", "v_or_b32 %5, %5, %8", "v_or_b32 %6, %6, %8", "v_or_b32 %7, %7, %8") \
+    X(SUB_U32,   "v_sub_u32 %0, %0, %8",                   "v_sub_u32 %1, %1, %8", "v_sub_u32 %2, %2, %8", "v_sub_u32 %3, %3, %8", "v_sub_u32 %4, %4, %8", "v_sub_u32 %5, %5, %8", "v_sub_u32 %6, %6, %8", "v_sub_u32 %7, %7, %8") \
+    X(LSHRREV,   "v_lshrrev_b32 %0, 3, %0",                "v_lshrrev_b32 %1, 3, %1", "v_lshrrev_b32 %2, 3, %2", "v_lshrrev_b32 %3, 3, %3", "v_lshrrev_b32 %4, 3, %4", "v_lshrrev_b32 %5, 3, %5", "v_lshrrev_b32 %6, 3, %6", "v_lshrrev_b32 %7, 3, %7") \
+    X(LSHL_ADD,  "v_lshl_add_u32 %0, %0, 3, %8",           "v_lshl_add_u32 %1, %1, 3, %8", "v_lshl_add_u32 %2, %2, 3, %8", "v_lshl_add_u32 %3, %3, 3, %8", "v_lshl_add_u32 %4, %4, 3, %8", "v_lshl_add_u32 %5, %5, 3, %8", "v_lshl_add_u32 %6, %6, 3, %8", "v_lshl_add_u32 %7, %7, 3, %8") \
+    X(ADD3,      "v_add3_u32 %0, %0, %8, %8",              "v_add3_u32 %1, %1, %8, %8", "v_add3_u32 %2, %2, %8, %8", "v_add3_u32 %3, %3, %8, %8", "v_add3_u32 %4, %4, %8, %8", "v_add3_u32 %5, %5, %8, %8", "v_add3_u32 %6, %6, %8, %8", "v_add3_u32 %7, %7, %8, %8") \
+    X(MUL_LO,    "v_mul_lo_u32 %0, %0, %8",                "v_mul_lo_u32 %1, %1, %8", "v_mul_lo_u32 %2, %2, %8", "v_mul_lo_u32 %3, %3, %8", "v_mul_lo_u32 %4, %4, %8", "v_mul_lo_u32 %5, %5, %8", "v_mul_lo_u32 %6, %6, %8", "v_mul_lo_u32 %7, %7, %8") \
+    X(MAD_U24,   "v_mad_u32_u24 %0, %0, %8, %8",           "v_mad_u32_u24 %1, %1, %8, %8", "v_mad_u32_u24 %2, %2, %8, %8", "v_mad_u32_u24 %3, %3, %8, %8", "v_mad_u32_u24 %4, %4, %8, %8", "v_mad_u32_u24 %5, %5, %8, %8", "v_mad_u32_u24 %6, %6, %8, %8", "v_mad_u32_u24 %7, %7, %8, %8") \
+    X(CVT_F32_U, "v_cvt_f32_u32 %0, %8",                   "v_cvt_f32_u32 %1, %8", "v_cvt_f32_u32 %2, %8", "v_cvt_f32_u32 %3, %8", "v_cvt_f32_u32 %4, %8", "v_cvt_f32_u32 %5, %8", "v_cvt_f32_u32 %6, %8", "v_cvt_f32_u32 %7, %8") \
+    X(PK_MUL,    "v_pk_mul_f32 %12, %12, %16",             "v_pk_mul_f32 %13, %13, %16", "v_pk_mul_f32 %12, %12, %16", "v_pk_mul_f32 %13, %13, %16", "v_pk_mul_f32 %12, %12, %16", "v_pk_mul_f32 %13, %13, %16", "v_pk_mul_f32 %12, %12, %16", "v_pk_mul_f32 %13, %13, %16") \
+    X(EXP,       "v_exp_f32 %0, %0",                       "v_exp_f32 %1, %1", "v_exp_f32 %2, %2", "v_exp_f32 %3, %3", "v_exp_f32 %4, %4", "v_exp_f32 %5, %5", "v_exp_f32 %6, %6", "v_exp_f32 %7, %7") \
+    X(SQRT,      "v_sqrt_f32 %0, %0",                      "v_sqrt_f32 %1, %1", "v_sqrt_f32 %2, %2", "v_sqrt_f32 %3, %3", "v_sqrt_f32 %4, %4", "v_sqrt_f32 %5, %5", "v_sqrt_f32 %6, %6", "v_sqrt_f32 %7, %7") \
+    X(ADD_F64,   "v_add_f64 %12, %12, %16",                "v_add_f64 %13, %13, %16", "v_add_f64 %12, %12, %16", "v_add_f64 %13, %13, %16", "v_add_f64 %12, %12, %16", "v_add_f64 %13, %13, %16", "v_add_f64 %12, %12, %16", "v_add_f64 %13, %13, %16") \
+    X(RCP_F64,   "v_rcp_f64 %12, %12",                     "v_rcp_f64 %13, %13", "v_rcp_f64 %12, %12", "v_rcp_f64 %13, %13", "v_rcp_f64 %12, %12", "v_rcp_f64 %13, %13", "v_rcp_f64 %12, %12", "v_rcp_f64 %13, %13") \
+    X(SAND_CND4, "s_and_b64 vcc, %10, exec\n v_cndmask_b32 %0, %0, %14, vcc\n v_cndmask_b32 %1, %1, %14, vcc\n v_cndmask_b32 %2, %2, %14, vcc\n v_cndmask_b32 %3, %3, %14, vcc", "s_and_b64 vcc, %10, exec\n v_cndmask_b32 %4, %4, %14, vcc\n v_cndmask_b32 %5, %5, %14, vcc\n v_cndmask_b32 %6, %6, %14, vcc\n v_cndmask_b32 %7, %7, %14, vcc", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0") \
+    X(CMP_CND4,  "v_cmp_le_f32 vcc, %0, %14\n v_cndmask_b32 %0, %0, %14, vcc\n v_cndmask_b32 %1, %1, %14, vcc\n v_cndmask_b32 %2, %2, %14, vcc\n v_cndmask_b32 %3, %3, %14, vcc", "v_cmp_le_f32 vcc, %4, %14\n v_cndmask_b32 %4, %4, %14, vcc\n v_cndmask_b32 %5, %5, %14, vcc\n v_cndmask_b32 %6, %6, %14, vcc\n v_cndmask_b32 %7, %7, %14, vcc", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0") \
+    X(SNOP,      "s_nop 0",                                "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0") \
     X(S_ADD,     "s_add_u32 %9, %9, 3",                 "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3") \
     X(S_AND64,   "s_and_b64 %10, %10, exec",              "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec")
 
@@ -178,6 +202,7 @@ int main(int argc, char** argv) {
         if (k == 0) { base4 = t[1]; base8 = t[2]; }
         printf("%-58s %9.3f %9.3f %9.3f | %7.2f %7.2f\n", kind_name[k], t[0], t[1], t[2], t[1] / base4, t[2] / base8);
     }
+    if (argc > 1 && std::string(argv[1]) == "valu") return 0;
     // ---- gathers
     std::vector<float> host(size_t(1) << 22);
     for (size_t i = 0; i < host.size(); i++) host[i] = float(i % 977) * 1e-3f;
