@@ -509,15 +509,14 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
         if (r.p.samples_per_item > r.p.spp) r.p.samples_per_item = r.p.spp;
         r.p.chunks = (r.p.spp + r.p.samples_per_item - 1) / r.p.samples_per_item;
         r.n_items = p0.probe_n ? p0.probe_n : uint32_t(my_tiles * 64 * r.p.chunks);
-        // Pool slots for this job.  Up to 2^20 items: one slot each (every path starts in iteration 0).  Beyond: ~items / 16 slots, at most
-        // pool_cap.  What a slot costs is the end-of-job drain -- the last ~8 iterations sweep a pool that is emptying -- i.e. ~8 P
-        // slot-iterations on top of the ~7 n the n paths need: 3 % at the 1024-spp bench job's 40 items per slot, but 23 % for the 128-spp
-        // share of an 8-way strong-scaled split if it kept the full 2^23 slots.  Fewer than ~2^20 slots stop filling the chip.
+        // Pool slots for this job: one per work item, at most pool_cap (2^23 by default).  (items_per_slot, a developer knob, default 1: a job of more
+        // than 2^20 items gets items / items_per_slot slots, at least 2^20 -- what a slot costs is the end-of-job drain, the last ~8 iterations sweep a
+        // pool that is emptying; measured in round 3, fewer slots than the job can fill lose more in short launches than they save in the drain.)
         {
             const uint64_t want64 = ((uint64_t(r.n_items) + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK) * WF_SHADE_BLOCK;
             uint64_t P = std::min<uint64_t>(want64, ctx->pool_cap);
             if (want64 > (1ull << 20)) {
-                const uint64_t by_items = (uint64_t(r.n_items) / ctx->items_per_slot) & ~uint64_t(16 * WF_SHADE_BLOCK - 1);
+                const uint64_t by_items = ((uint64_t(r.n_items) / ctx->items_per_slot) + 16 * WF_SHADE_BLOCK - 1) & ~uint64_t(16 * WF_SHADE_BLOCK - 1);   // (rounded UP: a job just over 2^20 items keeps one slot per item and its known length)
                 P = std::min<uint64_t>(P, std::max<uint64_t>(by_items, 1ull << 20));
             }
             mcpt_status ps = ensure_pool(ctx, ctx->lanes[k], uint32_t(P)); if (ps != MCPT_OK) return ps;

@@ -586,9 +586,11 @@ typedef _Float16 wf_h2 __attribute__((ext_vector_type(2)));
             const float t0z = fmaf(WF8_H(NZ, K), az, bz), t1z = fmaf(WF8_H(FZ, K), az, bz);                                  \
             const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 1e-4f));                                                      \
             const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));                                                       \
-            /* m = 2 m + (tn <= tf): the compare's carry shifted in by ONE add-with-carry (slot 7 first, so slot s ends up in bit s) */ \
-            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(tn), "v"(tf) : "vcc");      \
+            WF8_MASK_IN(tn, tf)                                                                                              \
         }
+/* m = 2 m + (tn <= tf): the compare's carry shifted in by ONE add-with-carry (slot 7 first, so slot s ends up in bit s).  (Round 4 A/B: the sign of
+   tf - tn shifted in by v_sub_f32 + v_alignbit_b32 -- a cheaper pair by the instruction prices of profiles/r04_uarch_probe.txt -- changed nothing.) */
+#define WF8_MASK_IN(TN, TF) asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(TN), "v"(TF) : "vcc");
 template <int N> struct WfKind { static constexpr int value = N; };
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, PathPool pool, IterCtl* ctl, uint32_t it, WaveTuning tune, DevCounters* gcnt,
@@ -754,7 +756,12 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(DM) / sizeof(DM[0])); k++) asm volatile("" :: "v"(DM[k]));
 #endif
-#ifdef WF_DUMMY_VALU    /* regime probe: N extra VALU issues per inner step (independent of everything, results discarded) */
+#ifdef WF_DUMMY_VNOP    /* regime probe: N v_nop per inner step -- VALU issue slots without operands, registers or a dependence chain */
+        {
+#pragma unroll
+          for (int k = 0; k < WF_DUMMY_VNOP; k++) asm volatile("v_nop"); }
+#endif
+#ifdef WF_DUMMY_VALU    /* regime probe: N extra DEPENDENT v_fma_f32 per inner step (one chain: adds issue slots AND ~N x the FMA latency to the wave's critical path) */
         { float dz = idx;
 #pragma unroll
           for (int k = 0; k < WF_DUMMY_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dz));
@@ -911,7 +918,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                     // merge registers, -1 ... -2 % step time); fetching b unconditionally as well is slower even where the registers are there
                     // (68 without the SLP vectoriser: 204.2 vs 201.4 ms -- half of the leaves have one triangle and the load is not free)
                     const float4 v0a = T[0], e1a = T[1], e2a = T[2];
-                    const float4* Tb = use_b ? T + 3 : T;                // (a lane without b reads a's record again: the same cache lines, no merge registers)
+                    const float4* Tb = use_b ? T + 3 : T;                // (a lane without b reads a's record again: the same cache lines, no merge registers; r04 A/B: all such lanes reading ONE fixed record instead: +-0)
                     const float4 v0b = Tb[0], e1b = Tb[1], e2b = Tb[2];
 #ifndef WF_SCHED_STATS
                     if (COUNT) n_tri += (use_a ? 1u : 0u) + (use_b ? 1u : 0u);
@@ -970,6 +977,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 }
 #undef OVF8
 #undef WF8_CHILD
+#undef WF8_MASK_IN
 #undef WF8_H
 #undef WF8_POP
 #undef WF8_PARK

@@ -67,6 +67,9 @@
     X(SAND_CND4, "s_and_b64 vcc, %10, exec\n v_cndmask_b32 %0, %0, %14, vcc\n v_cndmask_b32 %1, %1, %14, vcc\n v_cndmask_b32 %2, %2, %14, vcc\n v_cndmask_b32 %3, %3, %14, vcc", "s_and_b64 vcc, %10, exec\n v_cndmask_b32 %4, %4, %14, vcc\n v_cndmask_b32 %5, %5, %14, vcc\n v_cndmask_b32 %6, %6, %14, vcc\n v_cndmask_b32 %7, %7, %14, vcc", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0") \
     X(CMP_CND4,  "v_cmp_le_f32 vcc, %0, %14\n v_cndmask_b32 %0, %0, %14, vcc\n v_cndmask_b32 %1, %1, %14, vcc\n v_cndmask_b32 %2, %2, %14, vcc\n v_cndmask_b32 %3, %3, %14, vcc", "v_cmp_le_f32 vcc, %4, %14\n v_cndmask_b32 %4, %4, %14, vcc\n v_cndmask_b32 %5, %5, %14, vcc\n v_cndmask_b32 %6, %6, %14, vcc\n v_cndmask_b32 %7, %7, %14, vcc", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0") \
     X(SNOP,      "s_nop 0",                                "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0", "s_nop 0") \
+    X(PERM_VSEL, "v_perm_b32 %0, %8, %0, %14",           "v_perm_b32 %1, %8, %1, %14", "v_perm_b32 %2, %8, %2, %14", "v_perm_b32 %3, %8, %3, %14", "v_perm_b32 %4, %8, %4, %14", "v_perm_b32 %5, %8, %5, %14", "v_perm_b32 %6, %8, %6, %14", "v_perm_b32 %7, %8, %7, %14") \
+    X(FMA_MIX3V, "v_fma_mix_f32 %0, %8, %14, %0 op_sel_hi:[1,0,0]", "v_fma_mix_f32 %1, %8, %14, %1 op_sel_hi:[1,0,0]", "v_fma_mix_f32 %2, %8, %14, %2 op_sel_hi:[1,0,0]", "v_fma_mix_f32 %3, %8, %14, %3 op_sel_hi:[1,0,0]", "v_fma_mix_f32 %4, %8, %14, %4 op_sel_hi:[1,0,0]", "v_fma_mix_f32 %5, %8, %14, %5 op_sel_hi:[1,0,0]", "v_fma_mix_f32 %6, %8, %14, %6 op_sel_hi:[1,0,0]", "v_fma_mix_f32 %7, %8, %14, %7 op_sel_hi:[1,0,0]") \
+    X(MIN3_F32,  "v_min3_f32 %0, %0, %14, %15",          "v_min3_f32 %1, %1, %14, %15", "v_min3_f32 %2, %2, %14, %15", "v_min3_f32 %3, %3, %14, %15", "v_min3_f32 %4, %4, %14, %15", "v_min3_f32 %5, %5, %14, %15", "v_min3_f32 %6, %6, %14, %15", "v_min3_f32 %7, %7, %14, %15") \
     X(S_ADD,     "s_add_u32 %9, %9, 3",                 "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3", "s_add_u32 %9, %9, 3") \
     X(S_AND64,   "s_and_b64 %10, %10, exec",              "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec", "s_and_b64 %10, %10, exec")
 
