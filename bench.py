@@ -157,12 +157,19 @@ def cpu_baseline(pkg, cfg, scene, rays_per_path_ref, budget_s=20.0):
         _, c, t = o.render(spp, seed=2)
         rays = c["rays_primary"] + c["rays_continuation"] + c["rays_shadow"]
         omp_threads(1)
-        s1 = max(1, min(spp, int(6.0 / max(t1 * ncores * 0.7, 1e-3))))        # ~6 s of single-thread work (the oracle's OpenMP loop scales ~0.7 x cores: r03's / 8 guess cost 92 s on c5)
-        _, c1, tt1 = o.render(s1, seed=3)
+        # ~6 s of single-thread work (the oracle's OpenMP loop scales almost linearly: r03's / 8 guess cost 92 s on c5); where even ONE sample of the
+        # sampled film would take longer (c5: 33 s), the one-thread leg renders a quarter of its pixels
+        pred1 = t1 * ncores * 0.9
+        o1, w1, h1 = o, w, h
+        if pred1 > 8.0:
+            w1, h1 = max(16, w // 2), max(16, h // 2)
+            o1 = orc.Oracle(scene.with_resolution(w1, h1), max_depth=depth); pred1 /= 4.0
+        s1 = max(1, min(spp, int(6.0 / max(pred1, 1e-3))))
+        _, c1, tt1 = o1.render(s1, seed=3)
         omp_threads(ncores)
         rays1 = c1["rays_primary"] + c1["rays_continuation"] + c1["rays_shadow"]
         return {"value": round(rays / t / 1e6, 4), "unit": "Mray/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model(),
-                "threads_1": {"value": round(rays1 / tt1 / 1e6, 4), "mpath_per_s": round(c1["paths"] / tt1 / 1e6, 4), "spp": s1, "seconds": round(tt1, 2)},
+                "threads_1": {"value": round(rays1 / tt1 / 1e6, 4), "mpath_per_s": round(c1["paths"] / tt1 / 1e6, 4), "spp": s1, "film": "%dx%d" % (w1, h1), "seconds": round(tt1, 2)},
                 "sample": "%dx%dx%d spp of %s depth %d through oracle/mcpt_oracle.cpp (OpenMP, %d threads, %.2f s) [%s]" % (
                     w, h, spp, scene.name, depth, ncores, t, why),
                 "mpath_per_s": round(c["paths"] / t / 1e6, 4)}

@@ -15,10 +15,12 @@
 //   tri_isect  48 B / triangle   : v0.xyz,c | e1.xyz,_ | e2.xyz,_   (fp32; e = float(v_k - v_0) like Triangle.cpp:25-26)
 //                                  c = uint bits HIT_CLASS_* << 28: the lobe set BSDF::BSDF will build for this triangle's
 //                                  material (BSDF.cpp:95-107); the trace kernel ORs it into the triangle index of a closest hit
-//   tri_shade  64 B / triangle   : n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y material
+//   tri_shade 128 B / triangle   : ONE 128-B-aligned record = one cache line per shaded hit (round 4; r03: a 64-B shading record and a 32-B fp64 plane in two
+//                                  streams = two lines -- the L2 fetches whole 128-B lines for a gather, profiles/r04_fetch_calibration.txt):
+//                                  f4[0..3] n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y material
+//                                  f4[4..5] the triangle's fp64 plane (n.xyz, n.v0): the fp64 hit point of a shaded hit   f4[6..7] spare
 //   tri_pos64  72 B / triangle   : v0 v1 v2 in fp64 -- read once per shaded hit to form the fp64 hit point the
 //                                  reference's shadow-ray self-occlusion depends on (SURVEY A-9), and per light sample
-//   tri_plane64 32 B / triangle  : fp64 plane (n.xyz, n.v0): the fp64 hit point of a shaded hit in two 16-B loads
 //   tri_face    4 B / triangle   : leaf order -> face index of the input (Model::face order)
 #pragma once
 #include <stdint.h>
@@ -92,13 +94,13 @@ struct DevCamera {                 // Render::cast_Ray's per-frame constants hoi
 #define MCPT_N8_LO_SHIFT(slot) (8 * ((slot) & 1))        // bit position of its low-plane byte in that word
 #define MCPT_N8_HI_SHIFT(slot) (16 + 8 * ((slot) & 1))   // ... and of its high-plane byte
 #define MCPT_N8_EMPTY_WORD 0x0000ffffu                   // two empty slots: lo = 255, hi = 0 (an inverted box)
+#define MCPT_TRI_SHADE_F4 8                               // float4s per tri_shade record (128 B); the fp64 plane starts at float4 4
 struct DevScene {
     const float4* nodes;
     const float4* nodes8;
     const float4* tri_isect;
     const float4* tri_shade;
     const double* tri_pos64;
-    const double* tri_plane64;     // 4 doubles / triangle: n = (v1-v0) x (v2-v0) and n.v0, both fp64
     const int32_t* tri_face;
     const DevMaterial* mats;
     const DevLight* lights;

@@ -29,7 +29,7 @@ struct mcpt_ctx {
     int device = 0;
     mcpt_opts opts{};
     DevScene dev{};
-    DevBuf nodes, nodes8, tri_isect, tri_shade, tri_pos64, tri_plane64, tri_face, mats, lights, light_pos64, texels, accum_own, counters;
+    DevBuf nodes, nodes8, tri_isect, tri_shade, tri_pos64, tri_face, mats, lights, light_pos64, texels, accum_own, counters;
     float4* accum = nullptr;           // bound accumulator (own or external)
     hipStream_t own_stream = nullptr, stream = nullptr;
     // HIP-event brackets of the render calls whose duration has not been read yet: a ring, so that a call does not have to wait for the one
@@ -48,6 +48,7 @@ struct mcpt_ctx {
     // kernel of the other on the same CUs (measured +15 % on MI355X).
     struct WfLane {
         PathPool pool{};
+        CompactBufs compact{};             // scratch of the end-of-job drain compaction (wavefront.h); capacity 0 = none (small pools)
         std::vector<DevBuf> pool_bufs;
         DevBuf ctl_buf, ovf_buf;
         IterCtl* h_ctl = nullptr;          // pinned ring of control-block snapshots (termination check)
@@ -98,7 +99,7 @@ hipError_t upload(DevBuf& b, const std::vector<T>& v) {
 void destroy_ctx(mcpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    c->nodes.free_(); c->nodes8.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_plane64.free_(); c->tri_face.free_();
+    c->nodes.free_(); c->nodes8.free_(); c->tri_isect.free_(); c->tri_shade.free_(); c->tri_pos64.free_(); c->tri_face.free_();
     c->mats.free_(); c->lights.free_(); c->light_pos64.free_(); c->texels.free_(); c->accum_own.free_(); c->counters.free_();
     for (auto& L : c->lanes) {
         for (auto& b : L.pool_bufs) b.free_();
@@ -221,10 +222,10 @@ static mcpt_status finish_ctx(mcpt_ctx* c) {
     DevScene& d = c->dev;
     d.nodes = static_cast<const float4*>(c->nodes.p); d.nodes8 = static_cast<const float4*>(c->nodes8.p);
     d.tri_isect = static_cast<const float4*>(c->tri_isect.p);
-    d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p); d.tri_plane64 = static_cast<const double*>(c->tri_plane64.p);
+    d.tri_shade = static_cast<const float4*>(c->tri_shade.p); d.tri_pos64 = static_cast<const double*>(c->tri_pos64.p);
     d.tri_face = static_cast<const int32_t*>(c->tri_face.p); d.mats = static_cast<const DevMaterial*>(c->mats.p);
     d.lights = static_cast<const DevLight*>(c->lights.p); d.light_pos64 = static_cast<const double*>(c->light_pos64.p); d.texels = static_cast<const float4*>(c->texels.p);
-    c->info.device_bytes = c->nodes.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_plane64.bytes + c->tri_face.bytes +
+    c->info.device_bytes = c->nodes.bytes + c->nodes8.bytes + c->tri_isect.bytes + c->tri_shade.bytes + c->tri_pos64.bytes + c->tri_face.bytes +
                            c->mats.bytes + c->lights.bytes + c->light_pos64.bytes + c->texels.bytes + accum_bytes;
     return MCPT_OK;
 }
@@ -323,7 +324,6 @@ mcpt_status mcpt_create(const mcpt_scene_desc* scene, const mcpt_opts* opts, mcp
     if ((e = upload(c->tri_isect, hs.tri_isect)) != hipSuccess) return bail(e, "upload tri_isect");
     if ((e = upload(c->tri_shade, hs.tri_shade)) != hipSuccess) return bail(e, "upload tri_shade");
     if ((e = upload(c->tri_pos64, hs.tri_pos64)) != hipSuccess) return bail(e, "upload tri_pos64");
-    if ((e = upload(c->tri_plane64, hs.tri_plane64)) != hipSuccess) return bail(e, "upload tri_plane64");
     if ((e = upload(c->tri_face, hs.tri_face)) != hipSuccess) return bail(e, "upload tri_face");
     if ((e = upload(c->mats, hs.mats)) != hipSuccess) return bail(e, "upload materials");
     if ((e = upload(c->lights, hs.lights)) != hipSuccess) return bail(e, "upload lights");
@@ -364,9 +364,9 @@ mcpt_status mcpt_clone_to_device(mcpt_ctx* src, int32_t device, mcpt_ctx** out_c
     auto bail = [&](hipError_t he, const char* what) { mcpt_status s = hip_fail(he, what); destroy_ctx(c); return s; };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     auto t0 = std::chrono::steady_clock::now();
-    DevBuf* from[11] = {&src->nodes, &src->nodes8, &src->tri_isect, &src->tri_shade, &src->tri_pos64, &src->tri_plane64, &src->tri_face, &src->mats, &src->lights, &src->light_pos64, &src->texels};
-    DevBuf* to[11] = {&c->nodes, &c->nodes8, &c->tri_isect, &c->tri_shade, &c->tri_pos64, &c->tri_plane64, &c->tri_face, &c->mats, &c->lights, &c->light_pos64, &c->texels};
-    for (int i = 0; i < 11; i++) {
+    DevBuf* from[10] = {&src->nodes, &src->nodes8, &src->tri_isect, &src->tri_shade, &src->tri_pos64, &src->tri_face, &src->mats, &src->lights, &src->light_pos64, &src->texels};
+    DevBuf* to[10] = {&c->nodes, &c->nodes8, &c->tri_isect, &c->tri_shade, &c->tri_pos64, &c->tri_face, &c->mats, &c->lights, &c->light_pos64, &c->texels};
+    for (int i = 0; i < 10; i++) {
         if ((e = to[i]->alloc(from[i]->bytes)) != hipSuccess) return bail(e, "alloc scene stream");
         if (from[i]->bytes && (e = hipMemcpyPeer(to[i]->p, device, from[i]->p, src->device, from[i]->bytes)) != hipSuccess) return bail(e, "hipMemcpyPeer");
     }
@@ -434,12 +434,20 @@ static mcpt_status ensure_pool(mcpt_ctx* ctx, mcpt_ctx::WfLane& L, uint32_t P) {
     if (L.pool.P >= P) return MCPT_OK;
     HIP_TRY(hipStreamSynchronize(L.stream)); HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (auto& b : L.pool_bufs) { ctx->info.device_bytes -= b.bytes; b.free_(); }
-    L.pool_bufs.clear(); L.pool_bufs.resize(13);
-    void** dst[13] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sq_d, (void**)&L.pool.nee,
+    // the drain compaction's scratch: half a pool of the seven records a live slot carries from one iteration to the next (+ 4096 slots of rounding)
+    const bool want_compact = P >= 4 * WF_COMPACT_MIN_SLOTS && !(ctx->opts.flags & MCPT_FLAG_DETERMINISTIC) && env_u32("MCPT_WF_COMPACT", 1) != 0;
+    const uint32_t eighths = std::max(1u, std::min(7u, env_u32("MCPT_WF_COMPACT_EIGHTHS", 4)));      // compact when at most this many eighths of the swept slots are alive
+    const uint32_t ccap = want_compact ? uint32_t(uint64_t(P) * eighths / 8) + 4096 : 0;
+    L.compact = CompactBufs{}; L.compact.capacity = ccap; L.compact.eighths = eighths;
+    L.pool_bufs.clear(); L.pool_bufs.resize(22);
+    void** dst[22] = {(void**)&L.pool.ray_o, (void**)&L.pool.ray_d, (void**)&L.pool.hit, (void**)&L.pool.sq_d, (void**)&L.pool.nee,
                       (void**)&L.pool.L, (void**)&L.pool.beta, (void**)&L.pool.sum, (void**)&L.pool.ids, (void**)&L.pool.shadow_queue,
-                      (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o, (void**)&L.pool.block_items};
-    for (int i = 0; i < 13; i++) {
-        const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : i == 10 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : i == 12 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint2) : size_t(P) * 16;
+                      (void**)&L.pool.shadow_count, (void**)&L.pool.sq_o, (void**)&L.pool.block_items, (void**)&L.pool.live_cnt,
+                      (void**)&L.compact.beta, (void**)&L.compact.L, (void**)&L.compact.ray_d, (void**)&L.compact.ray_o, (void**)&L.compact.hit, (void**)&L.compact.nee,
+                      (void**)&L.compact.ids, (void**)&L.compact.dst_off};
+    for (int i = 0; i < 22; i++) {
+        const size_t bytes = i == 9 ? size_t(P) * sizeof(uint32_t) : (i == 10 || i == 13 || i == 21) ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint32_t) : i == 12 ? size_t(P / WF_SHADE_BLOCK) * sizeof(uint2)
+                           : i == 20 ? size_t(ccap) * sizeof(uint2) : (i >= 14 && i <= 19) ? size_t(ccap) * 16 : size_t(P) * 16;
         hipError_t e = L.pool_bufs[i].alloc(bytes);
         if (e != hipSuccess) { L.pool.P = 0; return hip_fail(e, "alloc path pool"); }
         if ((e = hipMemset(L.pool_bufs[i].p, 0, bytes)) != hipSuccess) { L.pool.P = 0; return hip_fail(e, "clear path pool"); }
@@ -487,7 +495,8 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
     const bool debug = env_u32("MCPT_WF_DEBUG", 0) != 0;
     const uint32_t max_it = env_u32("MCPT_WF_MAXIT", 1u << 20);
     DevCounters* cnt = static_cast<DevCounters*>(ctx->counters.p);
-    struct Run { RenderParams p; PathPool pool; uint32_t n_items = 0, n_shared = 0, it = 0, issued = 0, seen = 0, bound = 0, snap_it[RING] = {0}; size_t kev = 0; bool active = false, done = false; };
+    struct Run { RenderParams p; PathPool pool; uint32_t n_items = 0, n_shared = 0, it = 0, issued = 0, seen = 0, bound = 0, snap_it[RING] = {0}; size_t kev = 0; bool active = false, done = false;
+                 bool drain = false; };     // drain: a snapshot showed the shared work-item cursors exhausted -> the compaction launches follow every trace launch from here on
     std::vector<Run> runs(n_lanes);
     uint32_t n_active = 0;
     // A call with fewer samples than sub-pipelines (the reference's one-sample-per-call loop, Render.cpp:56-69) splits its TILES over them
@@ -573,13 +582,17 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             }
             const IterCtl& s = L.h_ctl[k];
             const uint32_t it_of = r.snap_it[k];                           // snapshot taken after iteration it_of
-            if (debug && r.seen < 40)
-                fprintf(stderr, "[wf] it=%u active=%u head=%u cursor0=%u/%u\n", it_of, s.any_active[it_of & 3],
-                        s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(r.n_shared, 0));
+            if (debug && (r.seen < 40 || s.pad[WF_CTL_P_ACTIVE]))
+                fprintf(stderr, "[wf] it=%u active=%u head=%u cursor0=%u/%u swept=%u live@compaction=%u compactions=%u\n", it_of, s.any_active[it_of & 3],
+                        s.trace_head[it_of & 3], s.item_cursor[0].v, wf_shard_capacity(r.n_shared, 0), s.pad[WF_CTL_P_ACTIVE], s.pad[WF_CTL_LIVE], s.pad[WF_CTL_COMPACTIONS]);
             if (s.pad[0]) return fail(MCPT_ERR_HIP, "trace kernel watchdog: a wave did not finish its ray list (internal error)");
             bool items_left = false;
             for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) items_left |= s.item_cursor[q].v < wf_shard_capacity(r.n_shared, q);
             if (s.any_active[it_of & 3] == 0 && !items_left) r.done = true;
+            // the compaction launches start as soon as the SHARED cursors move at all: a block turns to them when its private range (90 % of the items) is
+            // used up, i.e. in the last tenth of the job -- the host reads snapshots 4 - 8 iterations late, and a drain lasts about ten; the plan kernel
+            // itself waits until every item has been handed out
+            if (!r.drain) { uint64_t moved = 0; for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) moved += s.item_cursor[q].v; if (moved != 0 || !items_left) r.drain = true; }
             r.seen++;
         }
         return MCPT_OK;
@@ -598,6 +611,9 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             HIP_TRY(k_event(L, r, timed));
             HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(L.ovf_buf.p), L.stream));
             HIP_TRY(k_event(L, r, timed));
+            // end-of-job drain: move the live slots to the front of the pool once at most half of the swept ones are alive (decided on the device)
+            if (r.drain && !r.bound && L.compact.capacity && r.p.samples_per_item == 1 && !p0.probe_n)
+                HIP_TRY(launch_wf_compact(r.pool, L.compact, ctl, r.it, r.n_shared, r.p.priv_items, L.stream));
             r.it++;
             if (r.bound && r.it == r.bound) {                               // known-length job: all of it is enqueued; its verdict is read later
                 const uint32_t q = L.ring_next++ % RING;

@@ -183,9 +183,9 @@ DEV bool bvh_traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, in
 struct HitShade { f3 n; float tu, tv; int mat; bool front; };
 
 // Triangle::hit's record (Triangle.cpp:68-76): interpolated+normalised vertex normal (the shading normal, A-2),
-// uv, material.  One 64-B fetch.
+// uv, material.  One 64-B fetch (the first half of the triangle's 128-B shading record; its fp64 plane is the second half).
 DEV HitShade load_hit_shade(const DevScene& sc, int tri, float u, float v, f3 d) {
-    const float4* S = sc.tri_shade + 4 * (size_t)tri;
+    const float4* S = sc.tri_shade + MCPT_TRI_SHADE_F4 * (size_t)tri;
     const float4 a = S[0], b = S[1], c = S[2], e = S[3];
     const float w = 1.0f - u - v;
     HitShade h;
@@ -431,7 +431,7 @@ DEV LightSample sample_light(const LightData& ld, d3 p64, float xi_u, float xi_v
 // rounding noise in its low bits -- the two properties the self-occlusion statistics of SURVEY A-9 depend on (checked against the
 // real reference's images and self-occlusion rate by the tests) -- but costs two 16-B loads instead of five and a third of the flops.
 DEV d3 hit_point64_plane(const DevScene& sc, int tri, d3 o64, f3 dir) {
-    const double* P = sc.tri_plane64 + 4 * (size_t)tri;
+    const double* P = reinterpret_cast<const double*>(sc.tri_shade + MCPT_TRI_SHADE_F4 * (size_t)tri + 4);
     const d3 n = ld_d3(P); const double nd0 = P[3];
     const d3 dd = to_d3(dir);
     const double t = (nd0 - dot(n, o64)) * rcp64(dot(n, dd));

@@ -639,7 +639,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     // ---- streams in leaf order
     std::vector<uint32_t> ref_rank;
     if (out.reference_tie_order) reference_triangle_order(d, ref_rank);
-    out.tri_isect.assign(3 * size_t(nf) + 3, f4h{0.f, 0.f, 0.f, 0.f});    /* + one spare record: the trace kernel fetches triangles in pairs */ out.tri_shade.resize(4 * size_t(nf)); out.tri_pos64.resize(9 * size_t(nf)); out.tri_plane64.resize(4 * size_t(nf)); out.tri_face.resize(nf);
+    out.tri_isect.assign(3 * size_t(nf) + 3, f4h{0.f, 0.f, 0.f, 0.f});    /* + one spare record: the trace kernel fetches triangles in pairs */ out.tri_shade.assign(size_t(MCPT_TRI_SHADE_F4) * nf, f4h{0.f, 0.f, 0.f, 0.f}); out.tri_pos64.resize(9 * size_t(nf)); out.tri_face.resize(nf);
     parallel_for(nf, [&](uint32_t i_begin, uint32_t i_end) {
     for (uint32_t i = i_begin; i < i_end; i++) {
         const int f = order[i];
@@ -654,16 +654,17 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         out.tri_isect[3 * size_t(i) + 0] = {float(v0[0]), float(v0[1]), float(v0[2]), as_float(int((lobe_class << HIT_CLASS_SHIFT) | (out.reference_tie_order ? ref_rank[size_t(f)] : i)))};
         out.tri_isect[3 * size_t(i) + 1] = {float(w1[0] - w0[0]), float(w1[1] - w0[1]), float(w1[2] - w0[2]), 0.f};      // (edges from the world coordinates: Triangle.cpp:25-26's values)
         out.tri_isect[3 * size_t(i) + 2] = {float(w2[0] - w0[0]), float(w2[1] - w0[1]), float(w2[2] - w0[2]), 0.f};
-        out.tri_shade[4 * size_t(i) + 0] = {float(n0[0]), float(n0[1]), float(n0[2]), float(t0_[0])};
-        out.tri_shade[4 * size_t(i) + 1] = {float(n1[0]), float(n1[1]), float(n1[2]), float(t0_[1])};
-        out.tri_shade[4 * size_t(i) + 2] = {float(n2[0]), float(n2[1]), float(n2[2]), float(t1_[0])};
-        out.tri_shade[4 * size_t(i) + 3] = {float(t1_[1]), float(t2_[0]), float(t2_[1]), as_float(c[3])};
+        f4h* S = &out.tri_shade[size_t(MCPT_TRI_SHADE_F4) * i];
+        S[0] = {float(n0[0]), float(n0[1]), float(n0[2]), float(t0_[0])};
+        S[1] = {float(n1[0]), float(n1[1]), float(n1[2]), float(t0_[1])};
+        S[2] = {float(n2[0]), float(n2[1]), float(n2[2]), float(t1_[0])};
+        S[3] = {float(t1_[1]), float(t2_[0]), float(t2_[1]), as_float(c[3])};
         for (int a = 0; a < 3; a++) { out.tri_pos64[9 * size_t(i) + a] = v0[a]; out.tri_pos64[9 * size_t(i) + 3 + a] = v1[a]; out.tri_pos64[9 * size_t(i) + 6 + a] = v2[a]; }
         {
             const double ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2], bx = v2[0] - v0[0], by = v2[1] - v0[1], bz = v2[2] - v0[2];
             const double nx = ay * bz - by * az, ny = az * bx - bz * ax, nz = ax * by - bx * ay;
-            double* pl = &out.tri_plane64[4 * size_t(i)];
-            pl[0] = nx; pl[1] = ny; pl[2] = nz; pl[3] = nx * v0[0] + ny * v0[1] + nz * v0[2];
+            const double pl[4] = {nx, ny, nz, nx * v0[0] + ny * v0[1] + nz * v0[2]};
+            std::memcpy(&S[4], pl, sizeof pl);                              // the fp64 plane: second half of the record
         }
         out.tri_face[i] = f;
     }

@@ -14,9 +14,8 @@ struct HostScene {
     std::vector<f4h> nodes;          // 4 per inner node (binary tree: megakernel + probes)
     std::vector<f4h> nodes8;         // 5 per node of the 8-wide compressed tree (wavefront trace kernel)
     std::vector<f4h> tri_isect;      // 3 per triangle (leaf order)
-    std::vector<f4h> tri_shade;      // 4 per triangle
+    std::vector<f4h> tri_shade;      // MCPT_TRI_SHADE_F4 = 8 per triangle: shading record (4) + fp64 plane (2) + spare (2), device_scene.h
     std::vector<double> tri_pos64;   // 9 per triangle
-    std::vector<double> tri_plane64; // 4 per triangle
     std::vector<int32_t> tri_face;   // leaf order -> input face index
     std::vector<DevMaterial> mats;
     std::vector<DevLight> lights;

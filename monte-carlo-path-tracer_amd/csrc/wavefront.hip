@@ -118,7 +118,9 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     // later launch of the job ends here, before it streams the pool.  (An empty iteration used to cost 0.5 - 0.65 ms in this kernel and
     // 0.2 - 0.4 ms in the trace kernel: ~10 % of a 128-spp share of a strong-scaled job.)
     if (it != 0u && ctl->any_active[(it - 1u) & 3u] == 0u) return;
-    __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64], s_shadow_cnt[WF_SHADE_BLOCK / 64];
+    // after a drain compaction (wf_compact_*) the live slots sit at the front of the pool and only they are swept
+    { const uint32_t p_act = ctl->pad[WF_CTL_P_ACTIVE]; if (p_act != 0u && base >= p_act) return; }
+    __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64], s_shadow_cnt[WF_SHADE_BLOCK / 64], s_live_cnt[WF_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base, s_sel, s_scan, s_priv_base, s_priv_take, s_priv_next, s_priv_end;
     // the whole slot state of the block's 256-slot window, fetched coalesced in ONE batch by the slots' own lanes and handed to the
     // lanes that will process them through LDS: no dependent second round of (gathering) global loads after the sort ...
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
         {   // ---- phase 1: the hit record (Triangle.cpp:68-76), emitter MIS (Render.cpp:146-162), roulette rescale, first-hit emission
             const float4 h = s_hit[src];
             tri = __float_as_int(h.x) & HIT_TRI_MASK;
-            plane64 = reinterpret_cast<const double4*>(sc.tri_plane64)[tri];            // used a phase later: one dependent gather less in front of the light sample
+            plane64 = *reinterpret_cast<const double4*>(sc.tri_shade + MCPT_TRI_SHADE_F4 * (size_t)tri + 4);   // the second half of the hit's 128-B record (the same cache line as load_hit_shade's half); used a phase later
             const f3 d = xyz(s_rd[src]);
             const HitShade hs = load_hit_shade(sc, tri, h.y, h.z, d);                            // h.y, h.z: fp32 barycentrics of the traversal
             const float4 m1 = mats_lds ? s_mats[4 * hs.mat + 1] : reinterpret_cast<const float4*>(sc.mats)[4 * hs.mat + 1];   // radiance | flags
@@ -492,9 +494,14 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     //      block's four waves at the barrier for its round trip: 0.58 vs 0.24 ms per launch.)
     const uint32_t cur = it & 3;
     const uint64_t ms = __ballot(emit_shadow);
-    if (lane == 0) s_shadow_cnt[wv] = (uint32_t)__popcll(ms);                                   // (cells of their own: the item pull's s_wave_cnt may still be read by slower waves)
+    const uint64_t m_live = __ballot(state != SLOT_DEAD);
+    if (lane == 0) { s_shadow_cnt[wv] = (uint32_t)__popcll(ms); s_live_cnt[wv] = (uint32_t)__popcll(m_live); }   // (cells of their own: the item pull's s_wave_cnt may still be read by slower waves)
     __syncthreads();
-    if (tid == 0) { uint32_t tot = 0; for (uint32_t k = 0; k < WF_SHADE_BLOCK / 64; k++) tot += s_shadow_cnt[k]; st_s(&pool.shadow_count[blockIdx.x], tot); }
+    if (tid == 0) {
+        uint32_t tot = 0, live = 0;
+        for (uint32_t k = 0; k < WF_SHADE_BLOCK / 64; k++) { tot += s_shadow_cnt[k]; live += s_live_cnt[k]; }
+        st_s(&pool.shadow_count[blockIdx.x], tot); st_s(&pool.live_cnt[blockIdx.x], live);
+    }
     if (emit_shadow) {
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_shadow_cnt[k];
@@ -514,7 +521,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     }
     SH_TICK(5)                                                                                    // shadow-queue append + coalesced stores
     // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
-    const uint64_t ma = __ballot(state != SLOT_DEAD);
+    const uint64_t ma = m_live;
     const uint64_t m_term = __ballot(terminated), m_prim = __ballot(c_prim), m_cont = __ballot(c_cont);
     const uint64_t m_st = __ballot(c_self_t), m_sh = __ballot(c_self_h), m_shaded = __ballot(c_shaded);
     unsigned long long texels = 0;
@@ -622,7 +629,7 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
     const unsigned long long t_start = wall_clock64();
 #endif
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t P = pool.P;
+    const uint32_t P = ctl->pad[WF_CTL_P_ACTIVE] ? ctl->pad[WF_CTL_P_ACTIVE] : pool.P;      // (after a drain compaction: the live front of the pool)
     // Ray list = 2 * P / 256 chunks: chunk c < P/256 holds the extend rays of slots [256 c, 256 c + 256); chunk P/256 + b holds the
     // shadow rays shade block b queued (shadow_count[b] of them).  A wave owns one chunk at a time: the first statically (no atomic),
     // later ones from `head`.  A list with fewer chunks than waves (a small call: one sample per pixel of a small film) is handed out in
@@ -982,6 +989,86 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
 #undef WF8_POP
 #undef WF8_PARK
 #undef WF_TICK
+// ====================================================================================================== drain compaction (wavefront.h: CompactBufs)
+// Three small launches behind a trace launch, enqueued by the host once it has seen the shared work-item cursors run out; the first decides on the
+// device whether anything happens at all.
+//   plan  (one block)      every work item handed out (shared cursors AND every block's private range) and at most half of the swept slots alive?
+//                          -> exclusive prefix of the blocks' live counts = where each block's live slots go; the new sweep length (a multiple of 4096)
+//   move  (block per 256)  live slots -> scratch, in slot order
+//   back  (block per 256)  scratch -> the front of the pool; the slots between the last live one and the new sweep length are marked DEAD
+__global__ void __launch_bounds__(1024) wf_compact_plan_kernel(PathPool pool, CompactBufs cb, IterCtl* ctl, uint32_t it, uint32_t n_shared, uint32_t priv_items) {
+    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t s_sum[1024];
+    __shared__ uint32_t s_veto;
+    if (tid == 0) { s_veto = 0u; ctl->pad[WF_CTL_DO_COMPACT] = 0u; }
+    __syncthreads();
+    const uint32_t p_act = ctl->pad[WF_CTL_P_ACTIVE] ? ctl->pad[WF_CTL_P_ACTIVE] : pool.P;
+    if (ctl->any_active[it & 3u] == 0u || p_act < WF_COMPACT_MIN_SLOTS || it == 0u) return;      // job over / pool small (uniform: no barrier is skipped by part of the block)
+    const uint32_t nb = p_act / WF_SHADE_BLOCK, per = (nb + 1023u) / 1024u;
+    bool veto = false;
+    if (tid < WF_ITEM_SHARDS) veto = __hip_atomic_load(&ctl->item_cursor[tid].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wf_shard_capacity(n_shared, tid);
+    uint32_t mine = 0;
+    for (uint32_t b = tid * per; b < min(nb, (tid + 1u) * per); b++) {
+        mine += pool.live_cnt[b];
+        if (priv_items) { const uint2 r = pool.block_items[b]; veto = veto || r.x != r.y; }          // a block still holds private work items
+    }
+    if (veto) s_veto = 1u;
+    s_sum[tid] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {                                                // inclusive scan (Hillis-Steele; 10 rounds, once per drain iteration)
+        const uint32_t v = tid >= off ? s_sum[tid - off] : 0u;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t total = s_sum[1023];
+    if (s_veto != 0u || (unsigned long long)total * 8ull > (unsigned long long)p_act * cb.eighths || total > cb.capacity) return;
+    uint32_t run = s_sum[tid] - mine;
+    for (uint32_t b = tid * per; b < min(nb, (tid + 1u) * per); b++) { cb.dst_off[b] = run; run += pool.live_cnt[b]; }
+    if (tid == 0) {
+        ctl->pad[WF_CTL_LIVE] = total;
+        ctl->pad[WF_CTL_P_NEXT] = max((total + 4095u) & ~4095u, 4096u);
+        ctl->pad[WF_CTL_DO_COMPACT] = 1u;
+    }
+}
+__global__ void __launch_bounds__(WF_SHADE_BLOCK) wf_compact_move_kernel(PathPool pool, CompactBufs cb, IterCtl* ctl) {
+    if (ctl->pad[WF_CTL_DO_COMPACT] == 0u) return;
+    const uint32_t p_act = ctl->pad[WF_CTL_P_ACTIVE] ? ctl->pad[WF_CTL_P_ACTIVE] : pool.P;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, slot = blockIdx.x * WF_SHADE_BLOCK + tid;
+    if (blockIdx.x * WF_SHADE_BLOCK >= p_act) return;
+    __shared__ uint32_t s_cnt[WF_SHADE_BLOCK / 64];
+    const float4 bt = ld_s(&pool.beta[slot]);
+    const bool live = (__float_as_uint(bt.w) & 3u) != SLOT_DEAD;
+    const uint64_t m = __ballot(live);
+    if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (!live) return;
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < wv; k++) before += s_cnt[k];
+    const uint32_t dst = cb.dst_off[blockIdx.x] + before + lane_rank(m);
+    const uint2* id_ps = reinterpret_cast<const uint2*>(pool.ids);
+    st_s(&cb.beta[dst], bt); st_s(&cb.L[dst], ld_s(&pool.L[slot])); st_s(&cb.ray_d[dst], ld_s(&pool.ray_d[slot])); st_s(&cb.ray_o[dst], ld_s(&pool.ray_o[slot]));
+    st_s(&cb.hit[dst], ld_s(&pool.hit[slot])); st_s(&cb.nee[dst], ld_s(&pool.nee[slot])); st_s(&cb.ids[dst], ld_s(&id_ps[slot]));
+}
+__global__ void __launch_bounds__(WF_SHADE_BLOCK) wf_compact_back_kernel(PathPool pool, CompactBufs cb, IterCtl* ctl) {
+    if (ctl->pad[WF_CTL_DO_COMPACT] == 0u) return;
+    const uint32_t total = ctl->pad[WF_CTL_LIVE], p_next = ctl->pad[WF_CTL_P_NEXT];
+    const uint32_t i = blockIdx.x * WF_SHADE_BLOCK + threadIdx.x;
+    uint2* id_ps = reinterpret_cast<uint2*>(pool.ids);
+    if (i < total) {
+        st_s(&pool.beta[i], ld_s(&cb.beta[i])); st_s(&pool.L[i], ld_s(&cb.L[i])); st_s(&pool.ray_d[i], ld_s(&cb.ray_d[i])); st_s(&pool.ray_o[i], ld_s(&cb.ray_o[i]));
+        st_s(&pool.hit[i], ld_s(&cb.hit[i])); st_s(&pool.nee[i], ld_s(&cb.nee[i])); st_s(&id_ps[i], ld_s(&cb.ids[i]));
+    } else if (i < p_next) {                                                                        // padding up to the new sweep length: dead, no ray pending
+        st_s(&pool.beta[i], make_float4(0.f, 0.f, 0.f, __uint_as_float(SLOT_DEAD))); st_s(&pool.ray_d[i], make_float4(0.f, 0.f, 1.f, 0.f));
+    }
+    if (i == 0) { ctl->pad[WF_CTL_P_ACTIVE] = p_next; ctl->pad[WF_CTL_COMPACTIONS] += 1u; }          // (no other thread of this launch reads it)
+}
+hipError_t launch_wf_compact(const PathPool& pool, const CompactBufs& cb, IterCtl* ctl, uint32_t iteration, uint32_t n_shared, uint32_t priv_items, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_compact_plan_kernel, dim3(1), dim3(1024), 0, stream, pool, cb, ctl, iteration, n_shared, priv_items);
+    hipLaunchKernelGGL(wf_compact_move_kernel, dim3(pool.P / WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, stream, pool, cb, ctl);
+    hipLaunchKernelGGL(wf_compact_back_kernel, dim3((cb.capacity + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, stream, pool, cb, ctl);
+    return hipGetLastError();
+}
 // ====================================================================================================== launchers
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
                            float4* accum, DevCounters* cnt, hipStream_t stream) {

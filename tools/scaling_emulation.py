@@ -10,11 +10,18 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 steps = sys.argv[2] if len(sys.argv) > 2 else "2"
 shards = (sys.argv[3] if len(sys.argv) > 3 else "samples,tiles").split(",")
 XGMI_LINK_GBS = 153.0
-out = {"config": cfg, "method": __doc__.split("usage")[0].strip(), "rows": []}
+sys.path.insert(0, ROOT)
+import bench as _bench
+# the job that is split: the config's own spp where a step is the whole job (c2: 1024), else a slice of it 8 x the bench's step (c4: 1024 of 4096 spp,
+# c5: 256 of 16384) -- so that an 8-way split leaves every rank the bench's own step, not an eighth of a step that was already a reduced sample
+_cfg = _bench.CONFIGS[cfg]
+job_spp = min(_cfg["spp"], 8 * _cfg["step_spp"])
+out = {"config": cfg, "job_spp": None, "method": __doc__.split("usage")[0].strip(), "rows": []}
+out["job_spp"] = job_spp
 base = {}
 for shard in shards:
     for n in (1, 2, 4, 8):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", steps, "--warmup", "1", "--no-cpu-baseline", "--shard", shard]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", steps, "--warmup", "1", "--no-cpu-baseline", "--shard", shard, "--spp", str(job_spp)]
         if n > 1: cmd += ["--emulate-world", str(n), "--emulate-rank", "all"]
         line = subprocess.run(cmd, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
         d = json.loads(line)
