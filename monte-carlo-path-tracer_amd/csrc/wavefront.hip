@@ -888,9 +888,9 @@ __global__ void __launch_bounds__(WF_TRACE_BLOCK) wf_trace8_kernel(DevScene sc, 
                 // update as four selects: spelled with short-circuit `&&` and `if` the compiler built a branch per term and copied the hit state
                 // (tmax, triangle, u, v) at every join -- ~12 of ~64 VALU issues per triangle.  `u <= 1` of the any-hit rule is implied by
                 // v >= 0 and fl(u + v) <= 1 (rounding is monotone) and is not tested separately.
-                // KIND: 1 = every lane of this execution carries a closest-hit ray, 2 = every lane an any-hit ray, 0 = mixed.  A wave works through
-                // chunks of one kind (the extend rays come first in the list), so the mixed form is rare; the uniform forms drop the other rule's
-                // compares and -- any-hit -- all four selects.
+                // KIND: 2 = every lane of this execution carries an any-hit ray (no closest-hit rule, none of its selects), 0 = any mix -- the two forms
+                // that are instantiated.  (1 = "all closest-hit" is spelled out below but NOT instantiated: measured in round 3, a third form took the
+                // kernel from 74 to 86 registers and the closest-only + mixed pair alone was 2.5 % slower than the mixed form doing both jobs.)
                 // The verdicts live as LANE MASKS in SGPR pairs (accept, update, occluded) and every per-lane consequence is a select on such a mask.
                 auto leaf_test = [&](auto kind_c, const float4 v0, const float4 e1, const float4 e2, const int ti, const bool use, const uint64_t skip_lanes) __attribute__((always_inline)) {
                     constexpr int kind = decltype(kind_c)::value;

@@ -1135,6 +1135,34 @@ def test_shade_early_gathers_with_miss_lanes(pkg, orc):
         if name == "away": assert g[..., :3].max() == 0.0                # nothing is hit, nothing is shaded
 
 
+def test_drain_compaction_changes_nothing_but_the_sweep(pkg, tmp_path):
+    """Round 4: at the end of a job the live slots are moved to the front of the pool once at most half of the swept ones are alive, and the kernels
+    sweep only them (wf_compact_*).  A slot's number means nothing to the path it holds, so the film must be the film of the same
+    job without compaction up to fp32 summation order: S-cornell 1024x1024 x 6 spp (two sub-pipelines of 3 M items on pools of 3 M slots: big enough
+    for the compaction to be armed), MCPT_WF_COMPACT = 1 against 0 in two child processes (the knob is read when the pools are allocated); the run with
+    compaction must report at least one (MCPT_WF_DEBUG prints the control block's counters), every pixel keeps its 6 samples, ray counts are equal."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import __graft_entry__ as ge; pkg = ge.load_package();"
+            "r = pkg.Renderer(pkg.scenes.cornell_box(1024, 1024), max_depth=0); r.render(6, seed=5); a = r.read_accum(); c = r.counters(); r.close();"
+            "np.save(sys.argv[1], a); print('RAYS', c.rays, c.paths)") % root
+    films, rays, logs = [], [], []
+    for knob in ("1", "0"):
+        out = str(tmp_path / ("film%s.npy" % knob))
+        env = dict(os.environ, MCPT_WF_COMPACT=knob, MCPT_WF_DEBUG="1")
+        p = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        films.append(np.load(out)); rays.append([l for l in p.stdout.splitlines() if l.startswith("RAYS")][0]); logs.append(p.stderr)
+    import re
+    done = [int(x) for x in re.findall(r"compactions=(\d+)", logs[0])]
+    assert done and max(done) >= 1, "the compaction never ran: " + logs[0][-400:]
+    assert not [x for x in re.findall(r"compactions=(\d+)", logs[1]) if int(x) > 0]
+    a, b = films
+    assert np.all(a[..., 3] == 6) and np.all(b[..., 3] == 6)
+    assert rays[0] == rays[1], rays                                       # the same paths, ray for ray
+    assert np.allclose(a[..., :3], b[..., :3], rtol=2e-5, atol=1e-5)      # the same samples, summed in another order
+
+
 def test_facade_getPixelsColor_runs_on_the_device(pkg, tmp_path):
     """Round 4 (the reference's own loop, main.cpp:26-33: render(scene); getPixelsColor(); every frame): while the whole film is on the device
     Scene::getPixelsColor hands out the DEVICE's tonemap of it (mcpt_tonemap_map: kernel + 3 B per pixel into pinned memory) instead of reading
