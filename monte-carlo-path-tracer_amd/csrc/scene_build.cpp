@@ -49,7 +49,7 @@ inline float round_up(double v, float pad) { float f = float(v); if (double(f) <
 
 class Builder {
 public:
-    Builder(const std::vector<BTri>& t, std::vector<f4h>& nodes) : t_(t), nodes_(nodes), order_(t.size()) {
+    Builder(const std::vector<BTri>& t, std::vector<f4h>& nodes, int leaf_max = MCPT_LEAF_MAX) : leaf_max_(std::min(std::max(leaf_max, 1), MCPT_LEAF_MAX)), t_(t), nodes_(nodes), order_(t.size()) {
         for (size_t i = 0; i < order_.size(); i++) order_[i] = int(i);
     }
     void run() {
@@ -78,7 +78,7 @@ private:
     static constexpr int kBins = 16;
     static constexpr int kMaxDepth = 30;   // inner-node levels (the traversal stacks hold MCPT_STACK_DEPTH = 64: sentinel + one entry per level)
 
-    static int levels_needed(int n) { int l = 0; while ((MCPT_LEAF_MAX << l) < n) l++; return l; }
+    int levels_needed(int n) const { int l = 0; while ((leaf_max_ << l) < n) l++; return l; }
 
     void write_node(int idx, const Box& b0, int c0, const Box& b1, int c1) {
         auto pad_of = [](const Box& b) {
@@ -97,7 +97,7 @@ private:
     int build(int l, int r, int d, Box& box) {
         const int n = r - l;
         for (int i = l; i < r; i++) box.grow(t_[order_[i]].lo, t_[order_[i]].hi);
-        if (n <= MCPT_LEAF_MAX) {
+        if (n <= leaf_max_) {
             atomic_max(max_leaf_, uint32_t(n));
             return leaf_code(uint32_t(l), uint32_t(n));
         }
@@ -169,6 +169,7 @@ private:
     std::atomic<int> next_node_{0};
     std::atomic<uint32_t> depth_{0}, max_leaf_{0};
 
+    const int leaf_max_;                                               // triangles per binary leaf (the wide collapse may merge small subtrees again)
     const std::vector<BTri>& t_;
     std::vector<f4h>& nodes_;
     std::vector<int> order_;
@@ -210,23 +211,46 @@ inline float from_u32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 struct CollapsePlan {
     int K = 4;
     std::vector<unsigned char> split;                                   // [n * (K + 1) + i]
+    std::vector<int> merged_leaf;                                       // leaf formation (LeafCosts): binary node -> the leaf code its whole subtree becomes, 0 = stays a node
     unsigned char at(int n, int i) const { return split[size_t(n) * (K + 1) + i]; }
+    int leaf_of(int n) const { return merged_leaf.empty() ? 0 : merged_leaf[size_t(n)]; }
 };
-CollapsePlan plan_collapse(const std::vector<f4h>& n2, int K, const std::vector<int>& subtree_begin = std::vector<int>()) {
+// Leaf formation inside the dynamic programme (Ylitie et al. 2017, sec. 3.1): with `on`, a leaf child costs (visit + tri * triangles) node
+// visits per unit of relative area, and a binary subtree of <= MCPT_LEAF_MAX triangles that are consecutive in `order` may become ONE leaf
+// child where that is cheaper than keeping it a node.  Off, leaves cost nothing and stay as the binary builder made them.
+struct LeafCosts { bool on = false; double visit = 0.0, tri = 0.0; };
+CollapsePlan plan_collapse(const std::vector<f4h>& n2, int K, const std::vector<int>& subtree_begin = std::vector<int>(), const LeafCosts lc = LeafCosts()) {
     const int N = int(n2.size() / 4);
     CollapsePlan p; p.K = K; p.split.assign(size_t(N) * (K + 1), 0);
+    if (lc.on) p.merged_leaf.assign(size_t(N), 0);
     auto own_area = [&](int n) { Box3f a = box2(n2, n, 0); const Box3f b = box2(n2, n, 1); for (int x = 0; x < 3; x++) { a.lo[x] = std::min(a.lo[x], b.lo[x]); a.hi[x] = std::max(a.hi[x], b.hi[x]); } return area3(a); };
     const double root_area = std::max(own_area(0), 1e-300);
     std::vector<double> cost(size_t(N) * (K + 1), 0.0);
-    auto C = [&](int code, int i) { return code < 0 ? 0.0 : cost[size_t(code) * (K + 1) + i]; };   // a leaf is no node visit, in any number of slots
+    std::vector<uint32_t> span(lc.on ? size_t(N) : 0, 0);             // (first << 3 | count) of a subtree that could be one leaf, 0 = cannot
+    auto leaf_cost = [&](double area, uint32_t cnt) { return area / root_area * (lc.visit + lc.tri * double(cnt)); };
+    // cost of child k of node n in i slots: a node's from the table; a leaf is no node visit, in any number of slots (with LeafCosts: its own price)
+    auto C = [&](int n, int k, int i) {
+        const int code = child2(n2, n, k);
+        if (code >= 0) return cost[size_t(code) * (K + 1) + i];
+        return lc.on ? leaf_cost(area3(box2(n2, n, k)), uint32_t(~code) & 7u) : 0.0;
+    };
+    auto span_of = [&](int code) { return code < 0 ? uint32_t(~code) : span[size_t(code)]; };
     // The builder's renumbering puts every parent before its children, so descending index order is children first; below the top levels
     // every subtree is one contiguous index range (subtree_begin), and disjoint subtrees do not read each other's costs.
     auto range = [&](int lo, int hi) {
         for (int n = hi - 1; n >= lo; n--) {
-            const int l = child2(n2, n, 0), r = child2(n2, n, 1);
-            auto distribute = [&](int j, int& best_a) { double best = 1e300; for (int a = 1; a < j; a++) { const double c = C(l, a) + C(r, j - a); if (c < best) { best = c; best_a = a; } } return best; };
+            auto distribute = [&](int j, int& best_a) { double best = 1e300; for (int a = 1; a < j; a++) { const double c = C(n, 0, a) + C(n, 1, j - a); if (c < best) { best = c; best_a = a; } } return best; };
             int a = 1;
             cost[size_t(n) * (K + 1) + 1] = own_area(n) / root_area + distribute(K, a); p.split[size_t(n) * (K + 1) + 1] = (unsigned char)a;
+            if (lc.on) {
+                const uint32_t sl = span_of(child2(n2, n, 0)), sr = span_of(child2(n2, n, 1));
+                const uint32_t cl = sl & 7u, cr = sr & 7u;
+                if (n != 0 && cl && cr && cl + cr <= uint32_t(MCPT_LEAF_MAX) && (sr >> 3) == (sl >> 3) + cl) {
+                    span[size_t(n)] = ((sl >> 3) << 3) | (cl + cr);
+                    const double as_leaf = leaf_cost(own_area(n), cl + cr);
+                    if (as_leaf < cost[size_t(n) * (K + 1) + 1]) { cost[size_t(n) * (K + 1) + 1] = as_leaf; p.merged_leaf[size_t(n)] = ~int(span[size_t(n)]); }
+                }
+            }
             for (int i = 2; i <= K; i++) {
                 const double d = distribute(i, a), keep = cost[size_t(n) * (K + 1) + i - 1];
                 if (d < keep) { cost[size_t(n) * (K + 1) + i] = d; p.split[size_t(n) * (K + 1) + i] = (unsigned char)a; }
@@ -260,7 +284,7 @@ void planned_kids(const std::vector<f4h>& n2, const CollapsePlan& plan, int node
         const int c = child2(n2, it.parent, it.k);
         int i = it.slots;
         if (c >= 0) while (i > 1 && plan.at(c, i) == 0) i--;
-        if (c < 0 || i == 1) { kids.push_back({c, box2(n2, it.parent, it.k)}); continue; }
+        if (c < 0 || i == 1) { kids.push_back({c >= 0 && plan.leaf_of(c) ? plan.leaf_of(c) : c, box2(n2, it.parent, it.k)}); continue; }
         const int a = plan.at(c, i);
         todo.push_back({c, 1, i - a}); todo.push_back({c, 0, a});
     }
@@ -282,7 +306,10 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
     std::vector<f4h>& n2 = out.nodes;
     std::vector<f4h>& n8 = out.nodes8;
     const auto tb0 = std::chrono::steady_clock::now();
-    const CollapsePlan plan = plan_collapse(n2, 8, out.subtree_begin);
+    LeafCosts lc;                                                       // developer knobs: leaf formation in the collapse (see LeafCosts)
+    if (const char* e = std::getenv("MCPT_DP_LEAF_VISIT")) { lc.on = true; lc.visit = std::atof(e); }
+    if (const char* e = std::getenv("MCPT_DP_LEAF_TRI")) { lc.on = true; lc.tri = std::atof(e); }
+    const CollapsePlan plan = plan_collapse(n2, 8, out.subtree_begin, lc);
     if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build]   collapse plan (dynamic programme) %.0f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
     // Breadth-first, one level at a time: the nodes of a level are independent (children gathered from the plan, octant slots, quantised
     // planes: all threads), then one serial sweep over the level hands out the children's record numbers and the leaf triangles' positions
@@ -381,11 +408,11 @@ void build_bvh8(HostScene& out, std::vector<int>& order) {
             r[1].x = from_u32(uint32_t(n_rec)); r[1].y = from_u32(uint32_t(new_order.size()));
             for (int i = 0; i < em.n_inner; i++) next_level.push_back({em.inner2[i], int(n_rec++)});
             for (int i = 0; i < em.n_leaf; i++) {
-                new_first[em.leaf_first[i]] = int(new_order.size());
-                for (uint32_t t = 0; t < em.leaf_cnt[i]; t++) new_order.push_back(order[em.leaf_first[i] + t]);
+                for (uint32_t t = 0; t < em.leaf_cnt[i]; t++) { new_first[em.leaf_first[i] + t] = int(new_order.size()); new_order.push_back(order[em.leaf_first[i] + t]); }   // (every position: a merged leaf holds several binary leaves)
             }
         }
         n8.resize(5 * n_rec, f4h{0.f, 0.f, 0.f, 0.f});
+        if (std::getenv("MCPT_BUILD_DEBUG")) { size_t ni = 0, nl = 0, nt = 0; for (const Emit& em : emit) { ni += em.n_inner; nl += em.n_leaf; for (int i = 0; i < em.n_leaf; i++) nt += em.leaf_cnt[i]; } fprintf(stderr, "[build]   level %u: %zu nodes, %zu inner + %zu leaf children (%.2f of 8 slots), %zu triangles\n", out.bvh8_depth, emit.size(), ni, nl, double(ni + nl) / double(std::max<size_t>(1, emit.size())), nt); }
         level.swap(next_level);
     }
     // the new leaf order: every triangle stream and the binary tree's leaf codes follow it
@@ -587,7 +614,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
         if (!built) { out.nodes.clear(); order.clear(); }
     }
     if (!built) {
-        Builder b(bt, out.nodes);
+        Builder b(bt, out.nodes, std::getenv("MCPT_BIN_LEAF") ? std::atoi(std::getenv("MCPT_BIN_LEAF")) : MCPT_LEAF_MAX);
         b.run();
         if (std::getenv("MCPT_BUILD_DEBUG")) fprintf(stderr, "[build] SAH %.0f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         out.bvh_depth = b.depth; out.max_leaf = b.max_leaf;

@@ -109,6 +109,24 @@ def test_check_scene_on_every_generator(pkg):
         assert info.n_nodes <= max(1, s.n_faces)                  # a binary tree over <= 4-triangle leaves
 
 
+def test_leaf_formation_inside_the_collapse_keeps_the_tree_sound(pkg, monkeypatch):
+    """Developer knobs of the 8-wide collapse (scene_build.cpp, LeafCosts; DESIGN 5.0 'fuller nodes'): one-triangle binary leaves, and the
+    dynamic programme decides which subtrees of <= 3 triangles become ONE leaf child.  Measured: no faster than the default -- kept as a
+    knob, so it is kept sound: every triangle reachable exactly once inside every quantised box on its path (mcpt_check_scene's walk)."""
+    s = pkg.scenes.cornell_box(64, 64)
+    st, base, msg = pkg.check_scene(s)
+    assert st == 0, msg
+    for visit, tri in (("0", "0.3"), ("0.1", "0.5"), ("0", "1")):
+        monkeypatch.setenv("MCPT_BIN_LEAF", "1"); monkeypatch.setenv("MCPT_DP_LEAF_VISIT", visit); monkeypatch.setenv("MCPT_DP_LEAF_TRI", tri)
+        st, info, msg = pkg.check_scene(s)
+        assert st == 0, (visit, tri, msg)
+        assert info.n_tris == base.n_tris and info.n_nodes > base.n_nodes                   # the binary tree goes down to single triangles
+        assert 0.9 * base.wide_nodes <= info.wide_nodes <= 1.3 * base.wide_nodes           # ... and the collapse forms the leaves again
+    monkeypatch.setenv("MCPT_BIN_LEAF", "1"); monkeypatch.setenv("MCPT_DP_LEAF_VISIT", "0"); monkeypatch.setenv("MCPT_DP_LEAF_TRI", "0")
+    st, info, msg = pkg.check_scene(s)                                                      # free leaves: everything that fits is merged
+    assert st == 0 and info.wide_nodes <= base.wide_nodes * 1.02, msg
+
+
 def test_reference_undefined_behaviour_becomes_error_codes(pkg):
     s = pkg.scenes.open_box(8, 8)
     # no emissive triangle: the reference indexes lights[-1] (Render.cpp:204-206)
