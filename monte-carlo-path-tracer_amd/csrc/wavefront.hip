@@ -117,9 +117,8 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     // iteration has left no live slot -- a dead slot takes the next work item in the same call, so that also means no item is left -- every
     // later launch of the job ends here, before it streams the pool.  (An empty iteration used to cost 0.5 - 0.65 ms in this kernel and
     // 0.2 - 0.4 ms in the trace kernel: ~10 % of a 128-spp share of a strong-scaled job.)
-    if (it != 0u && ctl->any_active[(it - 1u) & 3u] == 0u) return;
-    // after a drain compaction (wf_compact_*) the live slots sit at the front of the pool and only they are swept
-    { const uint32_t p_act = ctl->pad[WF_CTL_P_ACTIVE]; if (p_act != 0u && base >= p_act) return; }
+    // After a drain compaction (wf_compact_*) the live slots sit at the front of the pool and only they are swept.
+    { const uint32_t p_act = ctl->pad[WF_CTL_P_ACTIVE]; if ((it != 0u && ctl->any_active[(it - 1u) & 3u] == 0u) || (p_act != 0u && base >= p_act)) return; }
     __shared__ uint32_t s_wave_cnt[WF_SHADE_BLOCK / 64], s_shadow_cnt[WF_SHADE_BLOCK / 64], s_live_cnt[WF_SHADE_BLOCK / 64];
     __shared__ uint32_t s_base, s_sel, s_scan, s_priv_base, s_priv_take, s_priv_next, s_priv_end;
     // the whole slot state of the block's 256-slot window, fetched coalesced in ONE batch by the slots' own lanes and handed to the
@@ -494,8 +493,8 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     //      block's four waves at the barrier for its round trip: 0.58 vs 0.24 ms per launch.)
     const uint32_t cur = it & 3;
     const uint64_t ms = __ballot(emit_shadow);
-    const uint64_t m_live = __ballot(state != SLOT_DEAD);
-    if (lane == 0) { s_shadow_cnt[wv] = (uint32_t)__popcll(ms); s_live_cnt[wv] = (uint32_t)__popcll(m_live); }   // (cells of their own: the item pull's s_wave_cnt may still be read by slower waves)
+    const uint32_t n_live = (uint32_t)__popcll(__ballot(state != SLOT_DEAD));
+    if (lane == 0) { s_shadow_cnt[wv] = (uint32_t)__popcll(ms); s_live_cnt[wv] = n_live; }   // (cells of their own: the item pull's s_wave_cnt may still be read by slower waves)
     __syncthreads();
     if (tid == 0) {
         uint32_t tot = 0, live = 0;
@@ -521,7 +520,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
     }
     SH_TICK(5)                                                                                    // shadow-queue append + coalesced stores
     // ---- bookkeeping: liveness flag (plain store) and ray counters (replicated per block => uncontended atomics)
-    const uint64_t ma = m_live;
+    const uint64_t ma = __ballot(state != SLOT_DEAD);
     const uint64_t m_term = __ballot(terminated), m_prim = __ballot(c_prim), m_cont = __ballot(c_cont);
     const uint64_t m_st = __ballot(c_self_t), m_sh = __ballot(c_self_h), m_shaded = __ballot(c_shaded);
     unsigned long long texels = 0;
@@ -573,8 +572,12 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
 //   * speculative traversal (Aila & Laine 2009): a lane parks the leaf group of a node in T and goes on with the node's inner children -- the
 //     leaf block tests the parked leaves of all lanes at once; the leaf group of a later node found while T is still occupied is pushed UNDER
 //     that node's inner group and parked when it is popped.
+// LDS budget (r04, profiles/r04_lds_budget.txt): 8 levels x 1024 lanes x 8 B = 64 KB of stack + 12.5 KB of top records + 2 KB = 78.5 KB of static
+// LDS per block (gfx950 addresses 160 KB per workgroup; the 64-KB habit of earlier rounds is not a limit here), beside two shade blocks of
+// 29.2 KB on the CU.  6 -> 8 levels: -3.4 % on the 4 M-triangle scene (depth-15 tree), -2.3 % at 93 k triangles, -0 ... -1 % on S-cornell;
+// 9 levels and more (>= 86 KB), or a larger record image (320 / 420 / 512 records), are SLOWER on every scene (+2 ... +8 %).
 #ifndef WF8_LDS_STACK
-#define WF8_LDS_STACK 6
+#define WF8_LDS_STACK 8
 #endif
 #ifndef MCPT_TOP_NODES8
 #define MCPT_TOP_NODES8 160         // records numbered breadth-first by the builder; 160 x 80 B = 12.5 KB of LDS
