@@ -389,9 +389,10 @@ def _needle_forest(pkg, n_needles=6000, seed=5):
 
 @pytest.mark.parametrize("tree", ["host-sah", "device-lbvh"])
 def test_probe_trace4_overflow_stack_and_random_rays(pkg, orc, tree):
-    """Rays that push the per-lane stack past its 12 LDS entries into the global overflow area (counted by the kernel), compared with
-    the binary-tree traversal on 200 000 rays and with the fp64 oracle (the reference's BVH::hit restated) on 3 000 of them."""
-    scene = _needle_forest(pkg)
+    """Rays that push the per-lane group stack past its LDS levels (WF8_LDS_STACK = 8 since r04: the forest is 80 000 needles, an 8-level
+    wide tree) into the global overflow area (counted by the kernel), compared with the binary-tree traversal on 200 000 rays and with
+    the fp64 oracle (the reference's BVH::hit restated) on 3 000 of them."""
+    scene = _needle_forest(pkg, n_needles=80000)
     rng = np.random.RandomState(11)
     n = 200_000
     o = np.stack([rng.uniform(0.2, 3.8, n), rng.uniform(-0.5, -0.1, n), rng.uniform(-0.5, 1.5, n)], 1)
