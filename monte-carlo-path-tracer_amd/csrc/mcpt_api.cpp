@@ -496,6 +496,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
     const uint32_t max_it = env_u32("MCPT_WF_MAXIT", 1u << 20);
     DevCounters* cnt = static_cast<DevCounters*>(ctx->counters.p);
     struct Run { RenderParams p; PathPool pool; uint32_t n_items = 0, n_shared = 0, it = 0, issued = 0, seen = 0, bound = 0, snap_it[RING] = {0}; size_t kev = 0; bool active = false, done = false;
+                 uint32_t grid = 0;         // blocks of this sub-pipeline's trace launches (below: small jobs share the CUs instead of queueing for them)
                  bool drain = false; };     // drain: a snapshot showed the shared work-item cursors exhausted -> the compaction launches follow every trace launch from here on
     std::vector<Run> runs(n_lanes);
     uint32_t n_active = 0;
@@ -555,6 +556,15 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
         r.active = true; n_active++;
     }
     for (Run& r : runs) if (r.active) r.p.atomic_accum = ((n_active > 1 && !split_tiles) || r.p.chunks > 1) ? 1u : 0u;
+    // Trace grid.  A CU holds ONE trace block (registers), so the trace launches of two sub-pipelines queue for each other's CUs.  That is what the steady
+    // state wants (the other pipeline's SHADE runs beside a trace launch); a job with about a ray per trace lane -- the one-sample frame of the reference's
+    // display loop: 320 k paths per sub-pipeline, 262 k trace lanes -- has nothing to hide and is a chain of 2 x (depth + 3) dependent launches: there each
+    // sub-pipeline's launch takes its share of the CUs and the chains run side by side.  S-cornell 800x800, render + tonemapped read per frame: 2.43 -> 2.06 ms;
+    // two samples per call 2.83 -> 2.76, four 3.95 -> 4.73 (profiles/r04_frame_knobs.txt): the split applies up to 2.5 paths per trace lane.  The same holds
+    // at the end of a long job once the drain compaction has shrunk the sweep that far (poll, below).
+    const uint32_t small_job = env_u32("MCPT_WF_SMALL_JOB_SPLIT", 1) && n_active > 1 ? uint32_t(std::min<uint64_t>(0xffffffffull, uint64_t(ctx->trace_grid) * wf_trace_block_threads() * 5 / 2)) : 0u;
+    const uint32_t shared_grid = std::max(1u, ctx->trace_grid / std::max(1u, n_active));
+    for (Run& r : runs) if (r.active) r.grid = (small_job && !p0.probe_n && r.n_items <= small_job) ? shared_grid : ctx->trace_grid;
     HIP_TRY(hipEventRecord(ctx->fork_ev, ctx->stream));
     for (uint32_t k = 0; k < n_lanes; k++) {
         if (!runs[k].active) continue;
@@ -592,6 +602,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             // the compaction launches start as soon as the SHARED cursors move at all: a block turns to them when its private range (90 % of the items) is
             // used up, i.e. in the last tenth of the job -- the host reads snapshots 4 - 8 iterations late, and a drain lasts about ten; the plan kernel
             // itself waits until every item has been handed out
+            if (small_job && s.pad[WF_CTL_P_ACTIVE] != 0u && s.pad[WF_CTL_P_ACTIVE] <= small_job) r.grid = shared_grid;   // (the compacted sweep of a draining job)
             if (!r.drain) { uint64_t moved = 0; for (uint32_t q = 0; q < WF_ITEM_SHARDS; q++) moved += s.item_cursor[q].v; if (moved != 0 || !items_left) r.drain = true; }
             r.seen++;
         }
@@ -609,7 +620,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
             HIP_TRY(k_event(L, r, timed));
             HIP_TRY(launch_wf_shade(ctx->dev, r.p, r.pool, ctl, r.it, r.n_shared, accum, cnt, L.stream));
             HIP_TRY(k_event(L, r, timed));
-            HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, ctx->trace_grid, static_cast<int*>(L.ovf_buf.p), L.stream));
+            HIP_TRY(launch_wf_trace(ctx->dev, r.pool, ctl, r.it, ctx->tune, count, cnt, r.grid, static_cast<int*>(L.ovf_buf.p), L.stream));
             HIP_TRY(k_event(L, r, timed));
             // end-of-job drain: move the live slots to the front of the pool once at most half of the swept ones are alive (decided on the device)
             if (r.drain && !r.bound && L.compact.capacity && r.p.samples_per_item == 1 && !p0.probe_n)
