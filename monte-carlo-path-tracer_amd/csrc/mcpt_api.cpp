@@ -570,10 +570,7 @@ static mcpt_status render_wavefront(mcpt_ctx* ctx, RenderParams& p0, float4* acc
         if (!runs[k].active) continue;
         mcpt_ctx::WfLane& L = ctx->lanes[k]; Run& r = runs[k];
         HIP_TRY(hipStreamWaitEvent(L.stream, ctx->fork_ev, 0));
-        HIP_TRY(hipMemsetAsync(L.ctl_buf.p, 0, sizeof(IterCtl), L.stream));
-        HIP_TRY(hipMemsetAsync(r.pool.beta, 0, size_t(r.pool.P) * 16, L.stream));    // every slot DEAD
-        HIP_TRY(hipMemsetAsync(r.pool.ids, 0, size_t(r.pool.P) * 16, L.stream));
-        HIP_TRY(hipMemsetAsync(r.pool.sum, 0, size_t(r.pool.P) * 16, L.stream));
+        HIP_TRY(launch_wf_pool_reset(r.pool, static_cast<IterCtl*>(L.ctl_buf.p), L.stream));    // every slot DEAD, control block zeroed
     }
     auto k_event = [&](mcpt_ctx::WfLane& L, Run& r, bool timed) -> hipError_t {
         if (!timed) return hipSuccess;

@@ -84,6 +84,7 @@ hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const Path
                            float4* accum, DevCounters* cnt, hipStream_t stream);
 hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,
                            DevCounters* cnt, uint32_t grid_blocks, int* stack_overflow, hipStream_t stream);
+hipError_t launch_wf_pool_reset(const PathPool& pool, IterCtl* ctl, hipStream_t stream);   // job start: every slot DEAD, control block zeroed
 hipError_t launch_wf_compact(const PathPool& pool, const CompactBufs& cb, IterCtl* ctl, uint32_t iteration, uint32_t n_shared, uint32_t priv_items, hipStream_t stream);
 int wf_trace_blocks_per_cu(bool count);
 uint32_t wf_trace_block_threads();

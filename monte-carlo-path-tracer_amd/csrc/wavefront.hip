@@ -1072,6 +1072,20 @@ hipError_t launch_wf_compact(const PathPool& pool, const CompactBufs& cb, IterCt
     hipLaunchKernelGGL(wf_compact_back_kernel, dim3((cb.capacity + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, stream, pool, cb, ctl);
     return hipGetLastError();
 }
+// Start of a job: every slot DEAD (beta.w = state 0), no ids, no partial sums, a zeroed control block -- ONE launch per sub-pipeline where four
+// hipMemsetAsync stood in line (a one-sample frame is a chain of ~25 dependent launches: four fewer per sub-pipeline).
+__global__ void __launch_bounds__(256) wf_pool_reset_kernel(PathPool pool, IterCtl* ctl) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < pool.P) { st_s(&pool.beta[i], z); st_s(&pool.sum[i], z); st_s(&pool.ids[i], make_uint4(0u, 0u, 0u, 0u)); }
+    if (i < sizeof(IterCtl) / 4) reinterpret_cast<uint32_t*>(ctl)[i] = 0u;
+}
+hipError_t launch_wf_pool_reset(const PathPool& pool, IterCtl* ctl, hipStream_t stream) {
+    static_assert(sizeof(IterCtl) % 4 == 0 && sizeof(IterCtl) / 4 <= 256 * 16, "the control block is cleared by the first blocks of the reset grid");
+    const uint32_t n = pool.P > uint32_t(sizeof(IterCtl) / 4) ? pool.P : uint32_t(sizeof(IterCtl) / 4);
+    hipLaunchKernelGGL(wf_pool_reset_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, pool, ctl);
+    return hipGetLastError();
+}
 // ====================================================================================================== launchers
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
                            float4* accum, DevCounters* cnt, hipStream_t stream) {

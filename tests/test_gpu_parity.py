@@ -844,6 +844,23 @@ def test_frame_by_frame_equals_one_call(pkg):
     assert np.array_equal(a[..., 3], b[..., 3]) and np.allclose(a, b, rtol=2e-5, atol=1e-5)
 
 
+def test_small_jobs_share_the_trace_grid_without_changing_the_film(pkg, monkeypatch):
+    """A job of about a path per trace lane (the one-sample frame of the reference's display loop, main.cpp:26-33) gives each sub-pipeline half of the
+    CUs for its trace launches (mcpt_api.cpp: Run::grid; DESIGN 6).  The grid is scheduling only: one sample per pixel, disjoint tile sets per
+    sub-pipeline -> the film is the same bit for bit with the split on and off, at the bounded depth (a job of known length) and at the
+    reference's unbounded depth (a polled job), and the next multi-sample call on the same context is untouched by it."""
+    scene = pkg.scenes.cornell_box_small(200, 120)
+    for depth in (5, 0):
+        films = []
+        for split in ("1", "0"):
+            monkeypatch.setenv("MCPT_WF_SMALL_JOB_SPLIT", split)
+            r = pkg.Renderer(scene, max_depth=depth)
+            for f in range(3):
+                r.render(1, seed=9, first_sample=f)
+            films.append(r.read_accum()); r.close()
+        assert np.all(films[0][..., 3] == 3) and np.array_equal(films[0], films[1]), depth
+
+
 def test_single_sample_calls_split_tiles_over_both_sub_pipelines(pkg, orc):
     """A call with one sample has nothing to split by sample index: the two sub-pipelines take alternate tiles of the call's share
     instead, and the loop runs its known number of iterations (max_depth + 3) before the first look at the control block.  Same film
