@@ -133,7 +133,12 @@ struct RenderParams {
     uint32_t probe_n;              // mcpt_probe_paths through the wavefront pipeline: item i (< probe_n) = "pixel" i of an n x 1 film,
     const double* probe_o;         //   whose one sample starts from the caller's ray (probe_o/probe_d: 3 doubles each) instead of
     const double* probe_d;         //   cast_Ray.  All three are 0 in a render.
+    // x / d for the three run-time divisors of the shade kernel's work-item decode as multiply + shift (filled by launch_wf_shade):
+    // {m, s} with x / d == (uint64(x) * m) >> s for every x < 2^30 (Granlund & Montgomery 1994: m = floor(2^(30 + L) / d) + 1, s = 30 + L,
+    // L = ceil(log2 d); m < 2^32).  The compiler's general 32-bit division is ~20 VALU instructions, and every shade wave runs all three.
+    uint32_t div_owned_m, div_owned_s, div_tiles_x_m, div_tiles_x_s, div_width_m, div_width_s;
 };
+#define MCPT_FASTDIV_MAX (1u << 30)   // exclusive bound on the dividends (work-item units, tiles, pixels: mcpt_create refuses larger films)
 
 struct DevCounters {               // mirrors the integer part of mcpt_counters
     unsigned long long paths, rays_primary, rays_continuation, rays_shadow, box_tests, tri_tests, shaded_hits,

@@ -529,6 +529,7 @@ mcpt_status build_host_scene(const mcpt_scene_desc* d, HostScene& out, std::stri
     if (!d || !d->vertex || !d->normal || !d->texcoord || !d->face || !d->materials || !d->textures) { err = "null pointer in mcpt_scene_desc"; return MCPT_ERR_INVALID_ARG; }
     if (d->n_face == 0 || d->n_materials == 0 || d->n_textures == 0) { err = "empty scene"; return MCPT_ERR_INVALID_ARG; }
     if (d->camera.width <= 0 || d->camera.height <= 0) { err = "camera width/height must be positive"; return MCPT_ERR_INVALID_ARG; }
+    if (uint64_t(d->camera.width) * uint64_t(d->camera.height) >= uint64_t(MCPT_FASTDIV_MAX)) { err = "film too large (limit 2^30 - 1 pixels)"; return MCPT_ERR_UNSUPPORTED; }
     if (d->n_face >= (1u << 28)) { err = "too many faces (limit 2^28-1)"; return MCPT_ERR_UNSUPPORTED; }
     const uint32_t nf = d->n_face;
 

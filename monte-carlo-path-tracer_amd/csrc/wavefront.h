@@ -88,4 +88,5 @@ hipError_t launch_wf_pool_reset(const PathPool& pool, IterCtl* ctl, hipStream_t 
 hipError_t launch_wf_compact(const PathPool& pool, const CompactBufs& cb, IterCtl* ctl, uint32_t iteration, uint32_t n_shared, uint32_t priv_items, hipStream_t stream);
 int wf_trace_blocks_per_cu(bool count);
 uint32_t wf_trace_block_threads();
+void wf_make_fastdiv(uint32_t d, uint32_t& m, uint32_t& s);   // exact x / d == (uint64(x) * m) >> s for x < MCPT_FASTDIV_MAX (RenderParams::div_*)
 size_t wf_trace_overflow_bytes_per_lane(uint32_t wide_depth);

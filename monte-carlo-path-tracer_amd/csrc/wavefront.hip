@@ -101,6 +101,8 @@ __device__ __forceinline__ int wf_sel(uint64_t mask, int if_set, int if_clear) {
 #define K_EMIT 1u
 #define K_DIFF 2u      // K_DIFF + lobe class (HIT_CLASS_*) = K_PHONG, K_MIRROR
 #define K_COUNT 5u
+// x / d by multiply + shift (RenderParams::div_*): exact for x < MCPT_FASTDIV_MAX
+__device__ __forceinline__ uint32_t wf_fastdiv(uint32_t x, uint32_t m, uint32_t s) { return (uint32_t)(((unsigned long long)x * m) >> s); }
 template <bool COUNT>
 __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade_kernel(DevScene sc, RenderParams p, PathPool pool, IterCtl* ctl, uint32_t it, uint32_t n_items,
                                                               float4* __restrict__ accum, DevCounters* gcnt) {
@@ -446,8 +448,9 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
                 } else if (mine || shared_item < n_items) {
                     const uint32_t n_tiles = p.n_owned;
                     const uint32_t iw = item >> 6, il = item & 63u;
-                    const uint32_t chunk = iw / n_tiles, tile = p.tile_rem + (iw - chunk * n_tiles) * p.tile_mod;
-                    const uint32_t px = (tile % p.tiles_x) * 8 + (il & 7), py = (tile / p.tiles_x) * 8 + (il >> 3);
+                    const uint32_t chunk = wf_fastdiv(iw, p.div_owned_m, p.div_owned_s), tile = p.tile_rem + (iw - chunk * n_tiles) * p.tile_mod;   // iw / n_tiles
+                    const uint32_t ty = wf_fastdiv(tile, p.div_tiles_x_m, p.div_tiles_x_s);                                                    // tile / tiles_x
+                    const uint32_t px = (tile - ty * p.tiles_x) * 8 + (il & 7), py = ty * 8 + (il >> 3);
                     if (px < (uint32_t)sc.cam.width && py < (uint32_t)sc.cam.height) {
                         id.x = py * (uint32_t)sc.cam.width + px;
                         id.z = p.first_sample + chunk * p.samples_per_item;
@@ -465,7 +468,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, MCPT_SHADE_MIN_WAVES) wf_shade
             nd = mk3((float)p.probe_d[3 * id.x], (float)p.probe_d[3 * id.x + 1], (float)p.probe_d[3 * id.x + 2]);
         } else {
             const Rng4 r = rng_block(id.x, id.y, 0u, p.seed_lo, p.seed_hi);
-            const int px = (int)(id.x % (uint32_t)sc.cam.width), py = (int)(id.x / (uint32_t)sc.cam.width);
+            const int py = (int)wf_fastdiv(id.x, p.div_width_m, p.div_width_s), px = (int)(id.x - (uint32_t)py * (uint32_t)sc.cam.width);   // id.x / width, id.x % width
             cast_ray(sc.cam, px, py, r.v[0], r.v[1], eye64, no, nd);                            // Render.cpp:64
         }
         s_ro[src] = mk4(no, __int_as_float(-1)); out_flags |= OUT_RAY_O;
@@ -1087,11 +1090,22 @@ hipError_t launch_wf_pool_reset(const PathPool& pool, IterCtl* ctl, hipStream_t 
     return hipGetLastError();
 }
 // ====================================================================================================== launchers
+// RenderParams::div_*: multiplier and shift of an exact x / d for x < 2^30 (d = 0 is treated as 1: such a call has no work items)
+void wf_make_fastdiv(uint32_t d, uint32_t& m, uint32_t& s) {
+    if (d == 0u) d = 1u;
+    uint32_t L = 0; while ((1ull << L) < d) L++;                          // ceil(log2 d)
+    s = 30u + L;
+    m = uint32_t(((1ull << s) / d) + 1ull);                               // < 2^31 + 2
+}
 hipError_t launch_wf_shade(const DevScene& sc, const RenderParams& p, const PathPool& pool, IterCtl* ctl, uint32_t iteration, uint32_t n_items,
                            float4* accum, DevCounters* cnt, hipStream_t stream) {
     const dim3 grid(pool.P / WF_SHADE_BLOCK), block(WF_SHADE_BLOCK);
-    if (p.flags & MCPT_FLAG_COUNT_TRAVERSAL) hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, stream, sc, p, pool, ctl, iteration, n_items, accum, cnt);
-    else hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, stream, sc, p, pool, ctl, iteration, n_items, accum, cnt);
+    RenderParams q = p;
+    wf_make_fastdiv(p.n_owned, q.div_owned_m, q.div_owned_s);
+    wf_make_fastdiv(p.tiles_x, q.div_tiles_x_m, q.div_tiles_x_s);
+    wf_make_fastdiv((uint32_t)sc.cam.width, q.div_width_m, q.div_width_s);
+    if (p.flags & MCPT_FLAG_COUNT_TRAVERSAL) hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, stream, sc, q, pool, ctl, iteration, n_items, accum, cnt);
+    else hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, stream, sc, q, pool, ctl, iteration, n_items, accum, cnt);
     return hipGetLastError();
 }
 hipError_t launch_wf_trace(const DevScene& sc, const PathPool& pool, IterCtl* ctl, uint32_t iteration, const WaveTuning& tune, bool count,

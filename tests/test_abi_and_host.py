@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import re
+import shutil
 import subprocess
 import tempfile
 
@@ -107,6 +108,23 @@ def test_check_scene_on_every_generator(pkg):
         assert info.n_tris == s.n_faces and info.n_lights >= 1
         assert info.max_leaf <= 4 and info.bvh_depth <= 30        # LDS traversal stack holds 32 entries
         assert info.n_nodes <= max(1, s.n_faces)                  # a binary tree over <= 4-triangle leaves
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_work_item_decode_divisions_are_exact(pkg, tmp_path):
+    """The shade kernel decodes a work item with three divisions by run-time values (tiles of the call, tiles per row, film width) done as
+    multiply + shift with constants the host computes per launch (wavefront.hip: wf_make_fastdiv): tests/fastdiv_check.cpp links the
+    library and checks x / d for 26 000 divisors against 4 million dividends below the 2^30 bound, multiples and their neighbours first."""
+    csrc = os.path.join(ROOT, "monte-carlo-path-tracer_amd", "csrc")
+    exe = str(tmp_path / "fastdiv_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "fastdiv_check.cpp"), "-o", exe, "-L" + csrc, "-lmcpt_hip",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+    # and the film-size bound the scheme rests on is enforced where scenes come in
+    s = pkg.scenes.open_box(8, 8)
+    st, _, msg = pkg.check_scene(s.with_resolution(32768, 32768))
+    assert st != 0 and "film too large" in msg, (st, msg)
 
 
 def test_leaf_formation_inside_the_collapse_keeps_the_tree_sound(pkg, monkeypatch):
