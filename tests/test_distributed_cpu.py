@@ -1,4 +1,4 @@
-"""CPU test of the N > 1 path (gloo, world_size 2): sample-range sharding + one film all-reduce per step reproduces the
+"""CPU test of the N > 1 path (gloo, world_size 2 and 4): sample-range sharding + one film all-reduce per step reproduces the
 single-process render of the union of the sample ranges.  The renderer here is the CPU oracle (no GPU in this container);
 bench.py runs the same two helpers (multigpu.first_sample / all_reduce_film) around the HIP renderer with backend nccl."""
 import os
@@ -30,6 +30,21 @@ def test_two_ranks_split_one_job(pkg, orc, tmp_path):
     import torch.multiprocessing as mp
     from tests import dist_worker
     world, job_spp, steps = 2, 5, 2
+    out = str(tmp_path / "film.npy")
+    mp.spawn(dist_worker.run, args=(world, _free_port(), job_spp, steps, out, True), nprocs=world, join=True)
+    film = np.load(out)
+    o = orc.Oracle(pkg.scenes.open_box(16, 16), max_depth=4)
+    want, _, _ = o.render(job_spp * steps, seed=11, first_sample=0, threads=1)
+    assert np.array_equal(film[..., 3], want[..., 3])
+    assert np.allclose(film[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
+
+
+def test_four_ranks_split_a_job_smaller_than_the_world(pkg, orc, tmp_path):
+    """A strong split with fewer samples than ranks (3 samples over 4 ranks: one rank renders nothing in a step and still takes part in the
+    film all-reduce) -- what `bench.py --gpus 8` does to a small job; the reduced film is the single-process render of the job."""
+    import torch.multiprocessing as mp
+    from tests import dist_worker
+    world, job_spp, steps = 4, 3, 2
     out = str(tmp_path / "film.npy")
     mp.spawn(dist_worker.run, args=(world, _free_port(), job_spp, steps, out, True), nprocs=world, join=True)
     film = np.load(out)
